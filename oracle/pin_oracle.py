@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Pins oracle/cpu_ref.cpp against the REAL reference (oracle/_ref/libref.so).
+
+Runs only where the reference checkout was present at build time (this container).
+Requires, for every scene below: identical PPM text bytes, bit-identical float colour
+buffers, and bit-identical (hit, leaf name, t, position, normal, ray_direction) for all
+primary rays and for seeded incoherent rays; plus the per-primitive known-answer probes
+of the reference's source/tests.cpp.  Exit code 0 = pinned.
+"""
+import hashlib
+import sys
+
+import numpy as np
+
+from oracle_lib import Port, Reference, SDF_DIR, random_rays
+
+SCENES = [
+    # (file, w, h, aa, bounces)
+    ("cornell.sdf", 480, 320, 4, 5),
+    ("cornell.sdf", 97, 61, 3, 2),
+    ("example.sdf", 480, 270, 1, 5),
+    ("example_fixed.sdf", 240, 135, 2, 5),
+    ("cornell_buster.sdf", 160, 90, 1, 5),
+    ("superhot_colored.sdf", 160, 90, 1, 5),
+]
+
+
+def beq(a, b):
+    """bitwise equality of float arrays (NaN == NaN, -0 != +0)"""
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def main():
+    port, ref = Port(), Reference()
+    ok = True
+    scenes = {}
+    for name, w, h, aa, nb in SCENES:
+        path = f"{SDF_DIR}/{name}"
+        if name not in scenes:
+            scenes[name] = (port.load(path), ref.load(path))
+        sp, sr = scenes[name]
+        a = port.render(sp, w, h, aa, nb)
+        b = ref.render(sr, w, h, aa, nb)
+        txt = port.ppm_text(a["rgb"])
+        same_txt = txt == b["ppm_text"]
+        same_cb = beq(a["color"], b["color"])
+        print(f"{name:22s} {w}x{h} aa={aa} b={nb}: ppm_text {'==' if same_txt else '!='} "
+              f"(md5 {hashlib.md5(b['ppm_text']).hexdigest()}), color_buffer bits {'==' if same_cb else '!='}, "
+              f"port {a['seconds']:.2f}s ref {b['seconds']:.2f}s")
+        if not same_cb:
+            d = np.abs(a["color"] - b["color"])
+            print("   max abs diff", np.nanmax(d), "n diff", int((a["color"].view(np.uint32) != b["color"].view(np.uint32)).sum()))
+        ok &= same_txt and same_cb
+
+    for name, (sp, sr) in scenes.items():
+        names = port.leaf_names(sp)
+        for label, (o, d) in {
+            "primary": port.primary_rays(sp, 240, 160, 1),
+            "random": random_rays(20000, 1234),
+        }.items():
+            if label == "primary":
+                o2, d2 = ref.primary_rays(sr, 240, 160, 1)
+                if not (beq(o, o2) and beq(d, d2)):
+                    print(f"{name}: primary ray generation differs")
+                    ok = False
+            a = port.intersect(sp, o, d)
+            b = ref.intersect(sr, o, d)
+            same_hit = np.array_equal(a["hit"], b["hit"])
+            a_names = [names[r] if r >= 0 else "null" for r in a["rank"]]
+            same_name = a_names == b["names"]
+            m = a["hit"]
+            fields = {k: beq(a[k][m], b[k][m]) for k in ("t", "pos", "normal", "raydir")}
+            print(f"{name:22s} {label:8s} rays={len(o)} hits={int(m.sum())} hit== {same_hit} name== {same_name} " +
+                  " ".join(f"{k}== {v}" for k, v in fields.items()))
+            ok &= same_hit and same_name and all(fields.values())
+
+    # per-primitive probes (source/tests.cpp:76-96, :112-142, :144-158, :217-259)
+    o, d = random_rays(5000, 99, lo=(-6, -6, -6), hi=(6, 6, 6))
+    prims = [
+        (0, [0, 0, 0, 1.5], []),
+        (0, [1, -2, 0.5, 2.0], [[1, 0.5, 0, -1], [3, 1.5, 0.7, 2.0]]),
+        (1, [-1, -1, -1, 1, 2, 3], []),
+        (1, [0, 0, 0, 2, 2, 2], [[1, 2, 1, -1], [2, 0.6, 0.2, -0.4]]),
+        (2, [-2, -3, -1, 1, -3, -1, -0.5, 2, -3], []),
+        (2, [-2, -3, -1, 1, -3, -1, -0.5, 2, -3], [[2, 0.3, 0.9, 0.1], [3, 2, 2, 0.5]]),
+    ]
+    for kind, p, xf in prims:
+        a = port.prim_intersect(kind, p, xf, o, d)
+        b = ref.prim_intersect(kind, p, xf, o, d)
+        m = a["hit"]
+        same = np.array_equal(a["hit"], b["hit"]) and all(beq(a[k][m], b[k][m]) for k in ("t", "pos", "normal", "raydir"))
+        print(f"prim kind={kind} xf={len(xf)} hits={int(m.sum())} identical={same}")
+        ok &= same
+    print("PINNED" if ok else "MISMATCH")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
