@@ -1,0 +1,212 @@
+/*
+ * ptx.h - C ABI of the MI355X (gfx950) render path.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++ or torch types.
+ * It replaces the body of the reference's Renderer::render (framework/renderer.cpp:25-59)
+ * and everything that call reaches on the CPU:
+ *     Renderer::thread_function / trace / shade / phong_color / reflection / refraction
+ *         (framework/renderer.cpp:61-291)
+ *     Composite::intersect            (framework/composite.cpp:75-103)
+ *     Sphere/Box/Triangle::intersect  (framework/sphere.cpp:35-52, box.cpp:89-165,
+ *                                      triangle.cpp:56-88)
+ * The reference has no FFI layer of its own; the seam is the C++ class Renderer
+ * (framework/renderer.hpp:22-62).  A host-side Renderer with that class's signatures
+ * flattens its Scene (framework/scene.hpp:13-21) into a PtxSceneDesc and calls the
+ * functions below; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns a PtxStatus; ptx_last_error() gives the message of the
+ *     calling thread's last failure.  Nothing throws across this boundary.
+ *   - matrices are 16 floats, column-major (element [col*4+row]), exactly the memory of
+ *     a glm::mat4 (Shape::world_transform_ / world_transform_inv_, framework/shape.hpp:39-40).
+ *   - pointers named d_* are DEVICE pointers (HBM); all others are host pointers.
+ *   - `stream` arguments are a hipStream_t passed as void* (NULL = the default stream).
+ *   - the library is built only for gfx950; with no such GPU every call that needs the
+ *     device fails with PTX_ERR_DEVICE (there is no CPU fallback).
+ */
+#ifndef PTX_H
+#define PTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtxStatus {
+	PTX_OK = 0,
+	PTX_ERR_INVALID = 1,     /* bad argument / malformed scene description            */
+	PTX_ERR_UNSUPPORTED = 2, /* scene shape this build does not flatten (see DESIGN)  */
+	PTX_ERR_DEVICE = 3,      /* HIP call failed, or no gfx950 device                  */
+	PTX_ERR_OVERFLOW = 4,    /* a ray queue filled up: result discarded, see message  */
+	PTX_ERR_NOMEM = 5
+} PtxStatus;
+
+/* Material (framework/material.hpp:10-27) */
+typedef struct PtxMaterial {
+	float ka[3], kd[3], ks[3];
+	float m, glossy, opacity, ior;
+} PtxMaterial;
+
+/* PointLight (framework/pointLight.hpp:6-12): intensity = color * brightness */
+typedef struct PtxLight {
+	float position[3];
+	float intensity[3];
+} PtxLight;
+
+/* Camera (framework/camera.hpp:8-14) */
+typedef struct PtxCamera {
+	float fov_x;
+	float position[3], direction[3], up[3];
+} PtxCamera;
+
+/*
+ * A frame is a Composite that changes coordinates and filters rays with its bounds_ box
+ * (framework/composite.cpp:75-103): frame 0 is scene.root, every other frame is a
+ * transformed child Composite of the root (a loaded OBJ mesh).  Octants and OBJ
+ * sub-objects (identity transform) are NOT frames; they only show up as `levels`.
+ *   bounds_min/max  the frame's bounds_ box, in its PARENT's space
+ *   levels_up       Composites between this frame and the root, the root included,
+ *                   the frame excluded (each one re-normalises the normal, :100)
+ */
+typedef struct PtxFrame {
+	float world[16];
+	float world_inv[16];
+	float bounds_min[3], bounds_max[3];
+	int32_t parent;    /* -1 for frame 0, 0 otherwise */
+	int32_t levels_up; /* 0 for frame 0 */
+} PtxFrame;
+
+typedef enum PtxPrimKind { PTX_SPHERE = 0, PTX_BOX = 1, PTX_TRIANGLE = 2 } PtxPrimKind;
+
+/*
+ * One leaf Shape.  The array order IS the tie-break order: element i is the i-th leaf met
+ * when walking the post-build_octree Composite tree depth first with children in
+ * std::map<std::string,...> order, duplicates (leaves that sit in several octants)
+ * listed once at their first encounter (framework/composite.hpp:35, composite.cpp:87-96).
+ *   p          sphere: center xyz, radius        (framework/sphere.hpp:22-23)
+ *              box: min xyz, max xyz             (framework/box.hpp:27-28)
+ *              triangle: v0, v1, v2              (framework/triangle.hpp:32-34)
+ *   normal     triangle only: n_                 (framework/triangle.hpp:35)
+ *   world/inv  the leaf's own transforms
+ *   frame      index of the frame the leaf lives in
+ *   levels_in  Composites between the leaf and its frame's own transform, i.e. the
+ *              octants/sub-objects above the leaf inside the frame; for frame 0 the
+ *              root itself is included (so levels_in >= 1 there)
+ */
+typedef struct PtxPrim {
+	int32_t kind;
+	int32_t material;
+	int32_t frame;
+	int32_t levels_in;
+	float p[9];
+	float normal[3];
+	float world[16];
+	float world_inv[16];
+} PtxPrim;
+
+typedef struct PtxSceneDesc {
+	const PtxFrame* frames;
+	int32_t n_frames;
+	const PtxPrim* prims;
+	int32_t n_prims;
+	const PtxMaterial* materials;
+	int32_t n_materials;
+	const PtxLight* lights;
+	int32_t n_lights;
+	float ambient[3]; /* Light::intensity of scene.ambient (framework/light.hpp:7-12) */
+	PtxCamera camera;
+} PtxSceneDesc;
+
+typedef struct PtxScene PtxScene; /* opaque: device-resident scene + work queues */
+
+/*
+ * What Renderer's constructor and render() fix for one image
+ * (framework/renderer.cpp:15-21, :74-86).  A sample is one (aax, aay) grid position of a
+ * pixel, numbered s = aax * aa_steps + aay; [sample_begin, sample_end) selects the part
+ * of the per-pixel sample grid this call renders (multi-GPU: one range per GPU).
+ */
+typedef struct PtxRenderParams {
+	uint32_t width, height;
+	uint32_t aa_steps;
+	uint32_t max_ray_bounces;
+	uint32_t sample_begin, sample_end; /* 0, aa_steps*aa_steps for the whole image */
+} PtxRenderParams;
+
+/* Work done by the last ptx_render_accumulate on this scene (whole call). */
+typedef struct PtxStats {
+	uint64_t samples;      /* primary rays                                           */
+	uint64_t trace_rays;   /* closest-hit queries (primary + reflection + refraction) */
+	uint64_t shadow_rays;  /* any-hit queries                                        */
+	uint64_t shaded_hits;  /* hits that were shaded                                  */
+	uint64_t launches;     /* bounce-kernel launches                                 */
+	uint64_t per_depth_rays[16];
+} PtxStats;
+
+const char* ptx_last_error(void);
+const char* ptx_version(void);
+
+/* Number of gfx950 devices visible (0 if none / no HIP runtime). Never fails. */
+int ptx_device_count(void);
+
+/*
+ * Validates and uploads a scene to `device`, builds the per-frame BVHs and allocates the
+ * ray queues.  queue_bytes = HBM budget for the ray queues (0 = default 4 GiB).
+ * Replaces the per-thread Scene copies of framework/renderer.cpp:48.
+ */
+PtxStatus ptx_scene_create(const PtxSceneDesc* desc, int device, uint64_t queue_bytes, PtxScene** out);
+void ptx_scene_destroy(PtxScene* scene);
+
+/*
+ * Adds, for every pixel, the sum over the selected samples of trace(primary ray)
+ * (framework/renderer.cpp:74-85) to d_accum (w*h*3 floats, row-major, y up, NOT cleared
+ * here).  Asynchronous on `stream` except for one final readback of the overflow flag
+ * and statistics when `stats` is non-NULL or check_overflow is non-zero.
+ */
+PtxStatus ptx_render_accumulate(PtxScene* scene, const PtxRenderParams* params, float* d_accum, void* stream,
+                                int check_overflow, PtxStats* stats);
+
+/*
+ * accum / spp -> tone map c/(c+1) (framework/renderer.cpp:86-89, :286-291) -> d_color
+ * (w*h*3 floats, the layout of Renderer::color_buffer()) and/or d_rgb8 (w*h*3 bytes, rows
+ * flipped and quantised as PpmWriter::write does, framework/ppmwriter.cpp:36-43).
+ * Either output may be NULL.
+ */
+PtxStatus ptx_resolve(int device, const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, float* d_color,
+                      uint8_t* d_rgb8, void* stream);
+
+/*
+ * Whole Renderer::render in one blocking call, host buffers out: color (w*h*3 floats)
+ * and/or rgb8 (w*h*3 bytes) may be NULL.  seconds (optional) = device time of the
+ * accumulate + resolve part.
+ */
+PtxStatus ptx_render_image(PtxScene* scene, const PtxRenderParams* params, float* color, uint8_t* rgb8,
+                           double* seconds, PtxStats* stats);
+
+/*
+ * scene.root->intersect(ray) for n rays (framework/renderer.cpp:109, shape.hpp:28).
+ * Host arrays; origins/dirs are n*3 floats.  prim = index into PtxSceneDesc::prims or -1;
+ * t = HitPoint::distance; pos / normal / raydir = HitPoint::position / surface_normal /
+ * ray_direction (framework/hitPoint.hpp:8-16).  Output pointers may be NULL.
+ */
+PtxStatus ptx_intersect(PtxScene* scene, int64_t n, const float* origins, const float* dirs, int32_t* prim, float* t,
+                        float* pos, float* normal, float* raydir);
+
+/*
+ * The primary ray of sample (aax, aay) = (sample / aa_steps, sample % aa_steps) of every
+ * pixel (framework/renderer.cpp:27-37, :76-82) intersected with the scene: prim (w*h
+ * int32) and t (w*h floats), pixel-major y up.  Host arrays, either may be NULL.
+ */
+PtxStatus ptx_primary_hits(PtxScene* scene, const PtxRenderParams* params, uint32_t sample, int32_t* prim, float* t);
+
+/* PpmWriter::save (framework/ppmwriter.cpp:55-76): ASCII P3 from the flipped rgb8 rows. */
+PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
+/* Introspection for tests and DESIGN numbers: BVH node / leaf-triangle counts, depth. */
+PtxStatus ptx_scene_info(const PtxScene* scene, int32_t* n_frames, int32_t* n_prims, int32_t* n_bvh_nodes,
+                         int32_t* max_bvh_depth, uint64_t* device_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_H */

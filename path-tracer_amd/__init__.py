@@ -1,0 +1,272 @@
+"""Python face of the MI355X render path (ctypes over the C ABI of include/ptx.h).
+
+The work is done by two in-tree shared libraries built by ``make -C path-tracer_amd/csrc``
+(or ``__graft_entry__.build()``):
+
+* ``libptx.so``      - HIP kernels for gfx950 + the C ABI (the drop-in boundary);
+* ``libpt_host.so``  - host-side C++ mirror of the reference's Scene / Shape / Composite /
+  Renderer API (scene loading, octree, flattening).
+
+There is no CPU implementation behind this module: if the libraries are missing, or no
+gfx950 device is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(_HERE)
+SDF_DIR = os.path.join(REPO, "fixtures", "sdf")
+
+PTX_OK = 0
+STATUS_NAMES = {0: "PTX_OK", 1: "PTX_ERR_INVALID", 2: "PTX_ERR_UNSUPPORTED", 3: "PTX_ERR_DEVICE", 4: "PTX_ERR_OVERFLOW", 5: "PTX_ERR_NOMEM"}
+
+# every symbol include/ptx.h declares (checked by tests/test_abi.py)
+PTX_SYMBOLS = [
+    "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
+    "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_scene_info",
+]
+
+
+class PtxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class PtxMaterial(C.Structure):
+    _fields_ = [("ka", C.c_float * 3), ("kd", C.c_float * 3), ("ks", C.c_float * 3), ("m", C.c_float), ("glossy", C.c_float),
+                ("opacity", C.c_float), ("ior", C.c_float)]
+
+
+class PtxLight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("intensity", C.c_float * 3)]
+
+
+class PtxCamera(C.Structure):
+    _fields_ = [("fov_x", C.c_float), ("position", C.c_float * 3), ("direction", C.c_float * 3), ("up", C.c_float * 3)]
+
+
+class PtxFrame(C.Structure):
+    _fields_ = [("world", C.c_float * 16), ("world_inv", C.c_float * 16), ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
+                ("parent", C.c_int32), ("levels_up", C.c_int32)]
+
+
+class PtxPrim(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("frame", C.c_int32), ("levels_in", C.c_int32), ("p", C.c_float * 9),
+                ("normal", C.c_float * 3), ("world", C.c_float * 16), ("world_inv", C.c_float * 16)]
+
+
+class PtxSceneDesc(C.Structure):
+    _fields_ = [("frames", C.POINTER(PtxFrame)), ("n_frames", C.c_int32), ("prims", C.POINTER(PtxPrim)), ("n_prims", C.c_int32),
+                ("materials", C.POINTER(PtxMaterial)), ("n_materials", C.c_int32), ("lights", C.POINTER(PtxLight)), ("n_lights", C.c_int32),
+                ("ambient", C.c_float * 3), ("camera", PtxCamera)]
+
+
+class PtxRenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aa_steps", C.c_uint32), ("max_ray_bounces", C.c_uint32),
+                ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32)]
+
+
+class PtxStats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("trace_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
+                ("launches", C.c_uint64), ("per_depth_rays", C.c_uint64 * 16)]
+
+    def as_dict(self):
+        return dict(samples=self.samples, trace_rays=self.trace_rays, shadow_rays=self.shadow_rays, shaded_hits=self.shaded_hits,
+                    launches=self.launches, per_depth_rays=list(self.per_depth_rays))
+
+
+_libs = {}
+
+
+def _load(name):
+    if name not in _libs:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: build it with `make -C path-tracer_amd/csrc` (there is no fallback path)")
+        _libs[name] = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return _libs[name]
+
+
+def ptx_lib():
+    L = _load("libptx.so")
+    if getattr(L, "_typed", False):
+        return L
+    vp = C.c_void_p
+    L.ptx_last_error.restype = C.c_char_p
+    L.ptx_version.restype = C.c_char_p
+    L.ptx_device_count.restype = C.c_int
+    L.ptx_scene_create.argtypes = [C.POINTER(PtxSceneDesc), C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.ptx_scene_destroy.argtypes = [vp]
+    L.ptx_scene_destroy.restype = None
+    L.ptx_render_accumulate.argtypes = [vp, C.POINTER(PtxRenderParams), vp, vp, C.c_int, C.POINTER(PtxStats)]
+    L.ptx_resolve.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.ptx_render_image.argtypes = [vp, C.POINTER(PtxRenderParams), vp, vp, C.POINTER(C.c_double), C.POINTER(PtxStats)]
+    L.ptx_intersect.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+    L.ptx_primary_hits.argtypes = [vp, C.POINTER(PtxRenderParams), C.c_uint32, vp, vp]
+    L.ptx_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.ptx_scene_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    L._typed = True
+    return L
+
+
+def host_lib():
+    ptx_lib()  # libpt_host.so links against libptx.so
+    H = _load("libpt_host.so")
+    if getattr(H, "_typed", False):
+        return H
+    H.pth_last_error.restype = C.c_char_p
+    H.pth_load_scene.restype = C.c_void_p
+    H.pth_load_scene.argtypes = [C.c_char_p, C.c_char_p]
+    H.pth_free_scene.argtypes = [C.c_void_p]
+    H.pth_free_scene.restype = None
+    H.pth_scene_desc.restype = C.POINTER(PtxSceneDesc)
+    H.pth_scene_desc.argtypes = [C.c_void_p]
+    H.pth_prim_name.restype = C.c_char_p
+    H.pth_prim_name.argtypes = [C.c_void_p, C.c_int]
+    H.pth_prim_path.restype = C.c_char_p
+    H.pth_prim_path.argtypes = [C.c_void_p, C.c_int]
+    H.pth_tree_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    H.pth_render_file.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, C.c_void_p, C.POINTER(C.c_double)]
+    H._typed = True
+    return H
+
+
+def _check(status):
+    if status != PTX_OK:
+        raise PtxError(status, ptx_lib().ptx_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None):
+    if sample_end is None:
+        sample_end = aa_steps * aa_steps
+    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end)
+
+
+class HostScene:
+    """load_scene() + flattening on the host (no GPU needed)."""
+
+    def __init__(self, sdf_path, obj_dir=None):
+        H = host_lib()
+        self._H = H
+        self.handle = H.pth_load_scene(os.fspath(sdf_path).encode(), obj_dir.encode() if obj_dir else None)
+        if not self.handle:
+            raise RuntimeError("load_scene failed: " + H.pth_last_error().decode())
+        self.desc = H.pth_scene_desc(self.handle)
+
+    def close(self):
+        if self.handle:
+            self._H.pth_free_scene(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_prims(self):
+        return self.desc.contents.n_prims
+
+    def prim_names(self):
+        return [self._H.pth_prim_name(self.handle, i).decode() for i in range(self.n_prims)]
+
+    def prim_paths(self):
+        return [self._H.pth_prim_path(self.handle, i).decode() for i in range(self.n_prims)]
+
+    def tree_stats(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._H.pth_tree_stats(self.handle, C.byref(a), C.byref(b), C.byref(c))
+        return dict(composites=a.value, leaf_entries=b.value, max_depth=c.value)
+
+    def render_file(self, w, h, aa, bounces, ppm_path=None, want_color=True):
+        """The reference's call sequence: Renderer{w,h,file,aa,bounces}.render(scene)."""
+        color = np.zeros((h, w, 3), np.float32) if want_color else None
+        sec = C.c_double(0)
+        rc = self._H.pth_render_file(self.handle, w, h, aa, bounces, ppm_path.encode() if ppm_path else None, _ptr(color), C.byref(sec))
+        if rc != 0:
+            raise RuntimeError(self._H.pth_last_error().decode())
+        return color, sec.value
+
+
+class DeviceScene:
+    """A scene resident on one GPU (ptx_scene_create)."""
+
+    def __init__(self, host_scene, device=0, queue_bytes=0):
+        self.L = ptx_lib()
+        self.host = host_scene
+        self.device = device
+        h = C.c_void_p()
+        _check(self.L.ptx_scene_create(host_scene.desc, device, queue_bytes, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.L.ptx_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        a, b, c, d, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        _check(self.L.ptx_scene_info(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
+        return dict(n_frames=a.value, n_prims=b.value, n_bvh_nodes=c.value, max_bvh_depth=d.value, device_bytes=e.value)
+
+    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None):
+        rp = render_params(w, h, aa, bounces, sample_begin, sample_end)
+        color = np.zeros((h, w, 3), np.float32)
+        rgb = np.zeros((h, w, 3), np.uint8)
+        sec = C.c_double(0)
+        st = PtxStats()
+        _check(self.L.ptx_render_image(self.handle, C.byref(rp), _ptr(color), _ptr(rgb), C.byref(sec), C.byref(st)))
+        return dict(color=color, rgb=rgb, seconds=sec.value, stats=st.as_dict())
+
+    def render_accumulate(self, rp, d_accum_ptr, stream=None, check_overflow=False, want_stats=False):
+        st = PtxStats() if want_stats else None
+        _check(self.L.ptx_render_accumulate(self.handle, C.byref(rp), C.c_void_p(d_accum_ptr), C.c_void_p(stream or 0), int(check_overflow),
+                                            C.byref(st) if st is not None else None))
+        return st.as_dict() if st is not None else None
+
+    def resolve(self, d_accum_ptr, w, h, spp, d_color_ptr=None, d_rgb_ptr=None, stream=None):
+        _check(self.L.ptx_resolve(self.device, C.c_void_p(d_accum_ptr), w, h, spp, C.c_void_p(d_color_ptr or 0), C.c_void_p(d_rgb_ptr or 0),
+                                  C.c_void_p(stream or 0)))
+
+    def intersect(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        prim = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float32)
+        pos = np.zeros((n, 3), np.float32)
+        nrm = np.zeros((n, 3), np.float32)
+        rd = np.zeros((n, 3), np.float32)
+        _check(self.L.ptx_intersect(self.handle, n, _ptr(o), _ptr(d), _ptr(prim), _ptr(t), _ptr(pos), _ptr(nrm), _ptr(rd)))
+        return dict(prim=prim, hit=prim >= 0, t=t, pos=pos, normal=nrm, raydir=rd)
+
+    def primary_hits(self, w, h, aa=1, sample=0):
+        rp = render_params(w, h, aa, 0)
+        prim = np.zeros(w * h, np.int32)
+        t = np.zeros(w * h, np.float32)
+        _check(self.L.ptx_primary_hits(self.handle, C.byref(rp), sample, _ptr(prim), _ptr(t)))
+        return prim, t
+
+
+def write_ppm(path, rgb):
+    h, w, _ = rgb.shape
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    _check(ptx_lib().ptx_write_ppm(os.fspath(path).encode(), _ptr(rgb), w, h))
+
+
+def device_count():
+    return ptx_lib().ptx_device_count()

@@ -1,0 +1,79 @@
+// extern "C" helpers over the host-side scene model, for callers without a C++ compiler in
+// the loop (the Python tests and bench.py load scenes through these).  The render path
+// itself is include/ptx.h; nothing here computes pixels.
+#include <cstring>
+#include <string>
+
+#include "flatten.hpp"
+#include "renderer.hpp"
+
+namespace {
+struct HostScene {
+	Scene scene;
+	FlatScene flat;
+};
+thread_local std::string g_err;
+}  // namespace
+
+extern "C" {
+
+const char* pth_last_error(void) { return g_err.c_str(); }
+
+// load_scene + flatten_scene.  obj_dir may be NULL (folder of the scene file).
+void* pth_load_scene(const char* sdf_path, const char* obj_dir) {
+	try {
+		auto* h = new HostScene{obj_dir ? load_scene(sdf_path, obj_dir) : load_scene(sdf_path), FlatScene{}};
+		try {
+			h->flat = flatten_scene(h->scene);
+		} catch (...) {
+			delete h;
+			throw;
+		}
+		return h;
+	} catch (SceneError const& e) {
+		g_err = e.message;
+	} catch (const char* msg) {
+		g_err = msg;
+	} catch (std::exception const& e) {
+		g_err = e.what();
+	}
+	return nullptr;
+}
+void pth_free_scene(void* h) { delete static_cast<HostScene*>(h); }
+
+const PtxSceneDesc* pth_scene_desc(void* h) { return &static_cast<HostScene*>(h)->flat.desc; }
+const char* pth_prim_name(void* h, int i) { return static_cast<HostScene*>(h)->flat.prim_names[(size_t) i].c_str(); }
+const char* pth_prim_path(void* h, int i) { return static_cast<HostScene*>(h)->flat.prim_paths[(size_t) i].c_str(); }
+void pth_tree_stats(void* h, int* composites, int* leaf_entries, int* max_depth) {
+	FlatScene const& f = static_cast<HostScene*>(h)->flat;
+	*composites = f.composites;
+	*leaf_entries = f.leaf_entries;
+	*max_depth = f.max_tree_depth;
+}
+
+// The drop-in call sequence of source/example.cpp:11-21: Renderer{w,h,file,aa,bounces}.render(scene).
+// color may be NULL.  Returns 0, or -1 with pth_last_error() set.
+int pth_render_file(void* h, unsigned w, unsigned hgt, unsigned aa, unsigned bounces, const char* ppm_path, float* color, double* device_seconds) {
+	try {
+		Renderer r{w, hgt, ppm_path ? ppm_path : "", aa, bounces};
+		r.set_output(ppm_path != nullptr);
+		r.render(static_cast<HostScene*>(h)->scene);
+		if (color) {
+			auto const& cb = r.color_buffer();
+			for (size_t i = 0; i < cb.size(); ++i) {
+				color[3 * i] = cb[i].r;
+				color[3 * i + 1] = cb[i].g;
+				color[3 * i + 2] = cb[i].b;
+			}
+		}
+		if (device_seconds) *device_seconds = r.device_seconds();
+		return 0;
+	} catch (const char* msg) {
+		g_err = msg;
+	} catch (SceneError const& e) {
+		g_err = e.message;
+	}
+	return -1;
+}
+
+}  // extern "C"

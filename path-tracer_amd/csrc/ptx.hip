@@ -1,0 +1,1205 @@
+// MI355X (gfx950) render path: device-resident scene, wavefront kernels and the C ABI of
+// include/ptx.h.  Replaces Renderer::render and everything it reaches
+// (framework/renderer.cpp:25-291, composite.cpp:75-103, sphere.cpp:35-52, box.cpp:89-165,
+// triangle.cpp:56-88 of the reference).
+//
+// Structure of one render
+//   for every batch of primary samples (pixel-major, sample-minor, so the 64 lanes of a
+//   wave are 64 samples of ONE pixel):
+//     k_bounce<depth 0>   generates the primary rays in registers (no primary-ray queue),
+//     k_bounce<depth d>   reads the rays of queue[d-1]; both then, per ray:
+//        closest hit      root leaves in lock step (wave-uniform scalar loads) + one
+//                         BVH2 walk per mesh frame with a per-lane stack in LDS
+//        shade            Phong + one any-hit shadow walk per light (inline, no shadow queue)
+//        emit             <= 2 weighted child rays (reflection / refraction) appended to
+//                         queue[d] with one wave64 ballot + one atomic per wave
+//        accumulate       weight * local colour, segmented wave reduction per pixel, then
+//                         one float atomicAdd per (pixel run, channel)
+//   k_resolve             accum / spp -> tone map -> float colour buffer + flipped 8-bit rows
+// No host synchronisation inside a render: ray counts stay in device memory and every
+// launch is a fixed persistent grid that strides over the count it reads.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ptx.h"
+#include "ptx_bvh.hpp"
+#include "ptx_device.hpp"
+
+using namespace ptxd;
+
+namespace {
+
+constexpr int kBlock = 256;  // 4 wave64 per workgroup
+constexpr int kStack = 32;   // per-lane BVH stack slots in LDS (>= ptx::kBvhMaxDepth)
+static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
+constexpr int kMaxDepthSlots = 16;
+
+// ---------------------------------------------------------------------------
+// device scene
+// ---------------------------------------------------------------------------
+struct DevRootPrim {  // a leaf of frame 0 (tested by every ray, wave-uniform access)
+	float winv[16];
+	float w[16];
+	float p[9];  // sphere: c, r | box: lo, hi | triangle: v0, e1, e2
+	float n[3];
+	int32_t kind, id, levels_in, material;
+};
+struct DevFrame {  // a transformed mesh Composite
+	float winv[16];
+	float w[16];
+	float bmin[3], bmax[3];
+	int32_t bvh_root;   // child reference, node indices relative to node_base
+	int32_t node_base;  // first float4 of this frame's nodes
+	int32_t tri_base;   // first float4 of this frame's triangle records
+	int32_t levels_up;
+	int32_t has_prims;
+	int32_t pad[3];
+};
+struct DevScene {
+	const DevRootPrim* root_prims;
+	const DevFrame* frames;
+	const float4* nodes;      // 4 float4 per node
+	const float4* tris;       // 3 float4 per triangle: (v0, e1.x) (e1.yz, e2.xy) (e2.z, id, -, -)
+	const float4* prim_info;  // per prim id: (n.x, n.y, n.z, bits(material | levels_in << 16))
+	const float4* materials;  // 4 float4 per material: (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
+	const float4* lights;     // 2 float4 per light: (pos, -) (intensity, -)
+	int32_t n_root_prims, n_frames, n_lights, n_prims;
+	float ambient[3];
+	float root_min[3], root_max[3];
+};
+
+struct DevCamera {  // Renderer::render's camera basis, framework/renderer.cpp:27-37
+	float m[16];    // trans_mat columns u, v, -dir, pos
+	float dist;     // img_plane_dist
+	float aa_unit;  // 1.0f / aa_steps
+	float half_w, half_h;
+	uint32_t width, height, aa_steps;
+};
+
+struct RayQueue {  // SoA of float4: each store/load is 16 B per lane, 1 KiB per wave, contiguous
+	float4* a;     // (o.x, o.y, o.z, d.x)
+	float4* b;     // (d.y, d.z, w.r, w.g)
+	float4* c;     // (w.b, bits(pixel), -, -)
+};
+
+struct Hit {
+	float t;
+	int32_t id;     // prim id (index into PtxSceneDesc::prims), -1 = miss
+	int32_t frame;  // 0 = root leaf
+	int32_t slot;   // root leaf: index into root_prims
+};
+
+struct Counters {  // cumulative over one ptx_render_accumulate
+	unsigned long long trace_rays, shadow_rays, shaded_hits, overflow;
+	unsigned long long per_depth[kMaxDepthSlots];
+};
+
+__device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+
+// ---------------------------------------------------------------------------
+// BVH walk.  The node test is a conservative filter (boxes are padded at build time and
+// the far limit carries a margin above the reference's epsilon), so which leaves get
+// tested never changes the answer: every triangle test is the reference's arithmetic and
+// the winner is min t, ties to the lowest prim id.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bvh_slab2(float4 q0, float4 q1, float4 q2, f3 inv, f3 noi, float limit, float& tn0, bool& h0,
+                                          float& tn1, bool& h1) {
+	float ax = __builtin_fmaf(q0.x, inv.x, noi.x), bx = __builtin_fmaf(q0.w, inv.x, noi.x);
+	float ay = __builtin_fmaf(q0.y, inv.y, noi.y), by = __builtin_fmaf(q1.x, inv.y, noi.y);
+	float az = __builtin_fmaf(q0.z, inv.z, noi.z), bz = __builtin_fmaf(q1.y, inv.z, noi.z);
+	tn0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+	float tf0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limit));
+	h0 = tn0 <= tf0;
+	float cx = __builtin_fmaf(q1.z, inv.x, noi.x), dx = __builtin_fmaf(q2.y, inv.x, noi.x);
+	float cy = __builtin_fmaf(q1.w, inv.y, noi.y), dy = __builtin_fmaf(q2.z, inv.y, noi.y);
+	float cz = __builtin_fmaf(q2.x, inv.z, noi.z), dz = __builtin_fmaf(q2.w, inv.z, noi.z);
+	tn1 = fmaxf(fmaxf(fminf(cx, dx), fminf(cy, dy)), fmaxf(fminf(cz, dz), 0.0f));
+	float tf1 = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), limit));
+	h1 = tn1 <= tf1;
+}
+
+// far limit for node culling given the best reported distance (reported = raw - kEps)
+__device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0f * kEps + 1e-5f * fabsf(best_t)); }
+
+template <bool ANY>
+__device__ __forceinline__ bool bvh_walk(const DevScene& S, const DevFrame& F, int frame, f3 o, f3 d, int* __restrict__ stk, Hit& best,
+                                         float range) {
+	const float4* __restrict__ nodes = S.nodes + F.node_base;
+	const float4* __restrict__ tris = S.tris + F.tri_base;
+	f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+	f3 noi = {-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)};
+	int sp = 0;
+	int cur = F.bvh_root;
+	float limit = ANY ? cull_limit(range) : cull_limit(best.t);
+	while (true) {
+		if (cur >= 0) {
+			const float4* nd = nodes + (size_t) cur * 4;
+			float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+			float tn0, tn1;
+			bool h0, h1;
+			bvh_slab2(q0, q1, q2, inv, noi, limit, tn0, h0, tn1, h1);
+			int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+			if (h0 && h1) {
+				if (tn1 < tn0) {
+					int tmp = c0;
+					c0 = c1;
+					c1 = tmp;
+				}
+				stk[sp * kBlock] = c1;
+				++sp;
+				cur = c0;
+				continue;
+			} else if (h0) {
+				cur = c0;
+				continue;
+			} else if (h1) {
+				cur = c1;
+				continue;
+			}
+		} else {
+			int v = ~cur;
+			int first = v >> 3, cnt = (v & 7) + 1;
+			for (int k = 0; k < cnt; ++k) {
+				const float4* tr = tris + (size_t) (first + k) * 3;
+				float4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
+				float t;
+				if (tri_t(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, t)) {
+					if (ANY) {
+						if (t <= range) return true;
+					} else {
+						int id = __float_as_int(r2.y);
+						if (t < best.t || (t == best.t && id < best.id)) {
+							best.t = t;
+							best.id = id;
+							best.frame = frame;
+							best.slot = first + k;
+							limit = cull_limit(t);
+						}
+					}
+				}
+			}
+		}
+		if (sp == 0) break;
+		--sp;
+		cur = stk[sp * kBlock];
+	}
+	return false;
+}
+
+// one leaf of frame 0 against a frame-0-space ray: the reference's per-shape intersect
+// up to the distance
+__device__ __forceinline__ bool root_prim_t(const DevRootPrim& P, f3 o, f3 d, float& t) {
+	f3 lo = xform_point(P.winv, o), ld = xform_dir(P.winv, d);
+	if (P.kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
+	if (P.kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
+	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
+}
+
+// scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103
+__device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
+	best.t = kInf;
+	best.id = -1;
+	best.frame = 0;
+	best.slot = 0;
+	float unused;
+	if (!box_slab(ld3(S.root_min), ld3(S.root_max), o, d, unused)) return;
+	for (int i = 0; i < S.n_root_prims; ++i) {
+		const DevRootPrim& P = S.root_prims[i];
+		float t;
+		if (root_prim_t(P, o, d, t)) {
+			if (t < best.t || (t == best.t && P.id < best.id)) {
+				best.t = t;
+				best.id = P.id;
+				best.frame = 0;
+				best.slot = i;
+			}
+		}
+	}
+	for (int f = 1; f < S.n_frames; ++f) {
+		const DevFrame& F = S.frames[f];
+		if (!F.has_prims) continue;
+		if (!box_slab(ld3(F.bmin), ld3(F.bmax), o, d, unused)) continue;
+		f3 lo = xform_point(F.winv, o), ld = xform_dir(F.winv, d);
+		bvh_walk<false>(S, F, f, lo, ld, stk, best, 0.0f);
+	}
+}
+
+// find_light_block(...).does_intersect, framework/renderer.cpp:168-175: the closest hit
+// lies within `range`  <=>  some leaf is hit at distance <= range.
+__device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
+	float t;
+	if (!box_slab(ld3(S.root_min), ld3(S.root_max), o, d, t)) return false;
+	for (int i = 0; i < S.n_root_prims; ++i) {
+		if (root_prim_t(S.root_prims[i], o, d, t) && t <= range) return true;
+	}
+	Hit dummy;
+	for (int f = 1; f < S.n_frames; ++f) {
+		const DevFrame& F = S.frames[f];
+		if (!F.has_prims) continue;
+		if (!box_slab(ld3(F.bmin), ld3(F.bmax), o, d, t)) continue;
+		f3 lo = xform_point(F.winv, o), ld = xform_dir(F.winv, d);
+		if (bvh_walk<true>(S, F, f, lo, ld, stk, dummy, range)) return true;
+	}
+	return false;
+}
+
+struct Surface {  // the HitPoint fields shading reads, framework/hitPoint.hpp:8-16
+	f3 pos, n, rdir;
+	int material;
+};
+
+// Rebuilds position / normal / ray_direction of the winning leaf exactly as the leaf and
+// the Composites above it would have produced them.
+__device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
+	Surface s;
+	int levels;
+	if (h.frame == 0) {
+		const DevRootPrim& P = S.root_prims[h.slot];
+		f3 lo = xform_point(P.winv, o), ld = xform_dir(P.winv, d);
+		if (P.kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
+			s.pos = xform_point(P.w, lo + ld * h.t);
+			s.n = normalize(s.pos - xform_point(P.w, ld3(P.p)));
+			s.rdir = d;
+		} else if (P.kind == PTX_BOX) {  // framework/box.cpp:98-100
+			f3 nl = box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t);
+			s.n = normalize(xform_dir(P.w, nl));
+			s.pos = o + d * h.t;
+			s.rdir = d;
+		} else {  // framework/triangle.cpp:86
+			s.pos = o + d * h.t;
+			s.rdir = ld;
+			s.n = xform_dir(P.w, ld3(P.n));
+		}
+		s.material = P.material;
+		levels = P.levels_in;
+	} else {
+		const DevFrame& F = S.frames[h.frame];
+		f3 lo = xform_point(F.winv, o), ld = xform_dir(F.winv, d);
+		float4 info = S.prim_info[h.id];
+		int packed = __float_as_int(info.w);
+		s.material = packed & 0xffff;
+		int lin = (packed >> 16) & 0xff;
+		f3 n = {info.x, info.y, info.z};
+		for (int k = 0; k < lin; ++k) n = normalize(n);  // octants / sub-objects, identity transform
+		s.n = normalize(xform_dir(F.w, n));               // the mesh Composite itself, composite.cpp:99-100
+		s.pos = xform_point(F.w, lo + ld * h.t);
+		s.rdir = ld;  // stays in mesh-local space: Composite never maps ray_direction back
+		levels = F.levels_up;
+	}
+	for (int k = 0; k < levels; ++k) s.n = normalize(s.n);  // identity-transform Composites up to the root
+	return s;
+}
+
+struct Material {
+	f3 ka, kd, ks;
+	float m, glossy, opacity, ior;
+};
+__device__ __forceinline__ Material load_material(const DevScene& S, int i) {
+	const float4* p = S.materials + (size_t) i * 4;
+	float4 a = p[0], b = p[1], c = p[2], e = p[3];
+	return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, c.y, c.z, c.w, e.x};
+}
+
+// Renderer::phong_color, framework/renderer.cpp:137-192.  A shadow query is skipped when the
+// light's term is exactly zero or back-facing: the reference traces it and then adds nothing.
+__device__ __forceinline__ f3 phong(const DevScene& S, const Surface& sf, const Material& M, int* __restrict__ stk, unsigned& n_shadow) {
+	f3 col = cmul(ld3(S.ambient), M.ka);
+	for (int l = 0; l < S.n_lights; ++l) {
+		float4 lp = S.lights[2 * l], li = S.lights[2 * l + 1];
+		f3 ldir = mk(lp.x, lp.y, lp.z) - sf.pos;
+		float dist = length(ldir);
+		ldir = normalize(ldir);
+		float c = dot(sf.n, ldir);
+		if (c < 0.0f) continue;
+		f3 I = {li.x, li.y, li.z};
+		f3 diffuse = cmul(I, M.kd) * c;
+		f3 spec = {0, 0, 0};
+		bool has_spec = false;
+		if (M.m != 0.0f) {  // specular_color, :177-192; pow is the double overload there
+			f3 r = 2 * dot(sf.n, ldir) * sf.n - ldir;
+			float cs = dot(r, sf.rdir * -1.0f);
+			if (!(cs < 0.0f)) {
+				float f = (float) pow((double) cs, (double) M.m);
+				spec = cmul(I, M.ks) * f;
+			}
+			has_spec = true;
+		}
+		if (!any_nonzero(diffuse) && !any_nonzero(spec)) continue;
+		++n_shadow;
+		if (trace_any(S, sf.pos, ldir, dist, stk)) continue;
+		col = col + diffuse;
+		if (has_spec) col = col + spec;
+	}
+	return col;
+}
+
+struct Child {
+	f3 o, d, w;
+	bool live;
+};
+
+// Renderer::shade, framework/renderer.cpp:113-135, with reflection (:194-201) and
+// refraction (:203-225) turned into weighted child rays: the child's colour enters the
+// parent linearly, so weight_child = weight * (factor the reference multiplies it by).
+__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, f3 weight, bool last_depth, int* __restrict__ stk, Child& refl,
+                                    Child& refr, unsigned& n_shadow) {
+	Material M = load_material(S, sf.material);
+	f3 c = phong(S, sf, M, stk, n_shadow) * M.opacity;
+	refl.live = false;
+	refr.live = false;
+	if (last_depth) return cmul(weight, c);
+
+	float w_refl = 0.0f, w_refr = 0.0f;  // scalar factors on reflection()*ks and refraction()*kd
+	bool want_refl = false, want_refr = false;
+	if (M.glossy > 0.0f && M.opacity < 1.0f) {
+		float R = schlick(sf.rdir, sf.n, M.ior);
+		c = c * (R * M.opacity);
+		w_refl = R;
+		w_refr = (1.0f - R) * (1.0f - M.opacity);
+		want_refl = want_refr = true;
+	} else if (M.glossy > 0.0f) {
+		float R = schlick(sf.rdir, sf.n, M.ior);
+		R = M.glossy + (1.0f - M.glossy) * R;
+		c = c * (1.0f - R);
+		w_refl = R;
+		want_refl = true;
+	} else if (M.opacity < 1.0f) {
+		c = c * M.opacity;
+		w_refr = 1.0f - M.opacity;
+		want_refr = true;
+	}
+	f3 wr = {0, 0, 0};  // total weight on the reflection ray
+	if (want_refl) wr = cmul(weight, M.ks) * w_refl;
+	if (want_refr) {
+		f3 rd = sf.rdir, n = sf.n;
+		float eta = 1.0f / M.ior;
+		float ci = -dot(n, rd);
+		if (ci < 0.0f) {
+			eta = 1.0f / eta;
+			ci *= -1.0f;
+			n = n * -1.0f;
+		}
+		float k = 1.0f - eta * eta * (1.0f - ci * ci);
+		if (k < 0.0f) {
+			// total internal reflection: refraction() returns reflection() (same ray, tinted by ks)
+			f3 extra = cmul(weight, M.ks);
+			if (M.glossy > 0.0f) extra = (extra * (1.0f - w_refl)) * (1.0f - M.opacity);
+			else extra = extra * w_refr;
+			wr = wr + extra;
+			want_refl = true;
+		} else {
+			f3 wt = cmul(weight, M.kd);
+			if (M.glossy > 0.0f) wt = (wt * (1.0f - w_refl)) * (1.0f - M.opacity);
+			else wt = wt * w_refr;
+			if (any_nonzero(wt)) {
+				refr.o = sf.pos - n * (2 * kEps);
+				refr.d = rd * eta + n * (eta * ci - __builtin_sqrtf(k));
+				refr.w = wt;
+				refr.live = true;
+			}
+		}
+	}
+	if (want_refl && any_nonzero(wr)) {
+		float ci = -dot(sf.n, sf.rdir);
+		refl.o = sf.pos;
+		refl.d = sf.rdir + (sf.n * ci * 2.0f);
+		refl.w = wr;
+		refl.live = true;
+	}
+	return cmul(weight, c);
+}
+
+// ---------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ unsigned long long lanes_below(unsigned lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
+
+// Adds `v` of the lanes with `has` into accum[pix*3..]: the wave is cut into runs of
+// consecutive lanes with equal pixel (rays stay in pixel order through compaction), each
+// run is summed with shuffles and its first lane issues the three atomics.
+__device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned pix, f3 v, bool has) {
+	if (__ballot(has) == 0) return;
+	unsigned lane = lane_id();
+	if (!has) v = mk(0, 0, 0);
+	unsigned up = __shfl_up(pix, 1);
+	bool head = lane == 0 || up != pix;
+	unsigned long long heads = __ballot(head);
+	unsigned seg = __builtin_popcountll(heads & (lanes_below(lane) | (1ull << lane)));  // run number, non-decreasing
+	int any = has ? 1 : 0;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		float ox = __shfl_down(v.x, off), oy = __shfl_down(v.y, off), oz = __shfl_down(v.z, off);
+		unsigned os = __shfl_down(seg, off);
+		int oa = __shfl_down(any, off);
+		if (lane + off < 64 && os == seg) {
+			v.x += ox;
+			v.y += oy;
+			v.z += oz;
+			any |= oa;
+		}
+	}
+	if (head && any) {
+		float* p = accum + (size_t) pix * 3;
+		atomicAdd(p, v.x);
+		atomicAdd(p + 1, v.y);
+		atomicAdd(p + 2, v.z);
+	}
+}
+
+__device__ __forceinline__ void make_primary(const DevCamera& cam, unsigned pixel, unsigned s, f3& o, f3& d) {
+	// framework/renderer.cpp:66-67, :76-82
+	unsigned x = pixel % cam.width, y = pixel / cam.width;
+	int aax = (int) (s / cam.aa_steps), aay = (int) (s % cam.aa_steps);
+	f3 pp = {x + aax * cam.aa_unit - cam.half_w, y + aay * cam.aa_unit - cam.half_h, -cam.dist};
+	f3 n = normalize(pp);
+	d = xform_dir(cam.m, n);
+	o = mk(cam.m[12], cam.m[13], cam.m[14]);
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+struct BounceArgs {
+	DevScene S;
+	DevCamera cam;
+	RayQueue in, out;
+	const unsigned* in_count;  // rays in `in` (depth > 0)
+	unsigned* out_count;       // rays appended to `out`
+	unsigned out_capacity;
+	unsigned long long first;  // depth 0: first linear sample index of the batch
+	unsigned batch;            // depth 0: samples in the batch
+	unsigned ns, s0;           // samples per pixel in this render's range, first sample
+	unsigned depth;
+	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
+	float* accum;
+	Counters* counters;
+};
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
+	__shared__ int lds_stack[kStack * kBlock];
+	int* stk = lds_stack + threadIdx.x;
+	const unsigned lane = lane_id();
+	const unsigned n = PRIMARY ? A.batch : min(*A.in_count, A.out_capacity);  // `in` has the same capacity as `out`
+	const unsigned waves_per_block = kBlock / 64;
+	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+	const unsigned n_waves = gridDim.x * waves_per_block;
+	unsigned cnt_trace = 0, cnt_shadow = 0, cnt_hits = 0;
+
+	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
+		unsigned i = (unsigned) base + lane;
+		bool active = i < n;
+		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
+		unsigned pix = 0;
+		if (active) {
+			if (PRIMARY) {
+				unsigned long long li = A.first + i;
+				pix = (unsigned) (li / A.ns);
+				unsigned s = A.s0 + (unsigned) (li - (unsigned long long) pix * A.ns);
+				make_primary(A.cam, pix, s, o, d);
+			} else {
+				float4 a = A.in.a[i], b = A.in.b[i], c = A.in.c[i];
+				o = mk(a.x, a.y, a.z);
+				d = mk(a.w, b.x, b.y);
+				w = mk(b.z, b.w, c.x);
+				pix = __float_as_uint(c.y);
+			}
+		}
+		Hit h;
+		h.id = -1;
+		if (active) {
+			trace_closest(A.S, o, d, stk, h);
+			++cnt_trace;
+		}
+		bool hit = active && h.id >= 0;
+		f3 contrib = {0, 0, 0};
+		Child refl, refr;
+		refl.live = refr.live = false;
+		if (hit) {
+			Surface sf = surface_of(A.S, o, d, h);
+			contrib = shade(A.S, sf, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
+			++cnt_hits;
+		}
+		accumulate(A.accum, pix, contrib, hit);
+
+		// wave64 ballot compaction of the child rays: a lane's two children stay adjacent
+		unsigned long long m1 = __ballot(refl.live), m2 = __ballot(refr.live);
+		unsigned total = __builtin_popcountll(m1) + __builtin_popcountll(m2);
+		if (total) {
+			unsigned slot0 = 0;
+			if (lane == 0) slot0 = atomicAdd(A.out_count, total);
+			slot0 = __shfl(slot0, 0);
+			unsigned long long lt = lanes_below(lane);
+			unsigned my = slot0 + __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
+			if (refl.live) {
+				if (my < A.out_capacity) {
+					A.out.a[my] = make_float4(refl.o.x, refl.o.y, refl.o.z, refl.d.x);
+					A.out.b[my] = make_float4(refl.d.y, refl.d.z, refl.w.x, refl.w.y);
+					A.out.c[my] = make_float4(refl.w.z, __uint_as_float(pix), 0.f, 0.f);
+				}
+				++my;
+			}
+			if (refr.live && my < A.out_capacity) {
+				A.out.a[my] = make_float4(refr.o.x, refr.o.y, refr.o.z, refr.d.x);
+				A.out.b[my] = make_float4(refr.d.y, refr.d.z, refr.w.x, refr.w.y);
+				A.out.c[my] = make_float4(refr.w.z, __uint_as_float(pix), 0.f, 0.f);
+			}
+			if (lane == 0 && slot0 + total > A.out_capacity) atomicAdd(&A.counters->overflow, 1ull);
+		}
+	}
+	// per-wave statistics: one atomic per counter per wave
+	for (int off = 32; off > 0; off >>= 1) {
+		cnt_trace += __shfl_down(cnt_trace, off);
+		cnt_shadow += __shfl_down(cnt_shadow, off);
+		cnt_hits += __shfl_down(cnt_hits, off);
+	}
+	if (lane == 0 && cnt_trace) {
+		atomicAdd(&A.counters->trace_rays, (unsigned long long) cnt_trace);
+		atomicAdd(&A.counters->shadow_rays, (unsigned long long) cnt_shadow);
+		atomicAdd(&A.counters->shaded_hits, (unsigned long long) cnt_hits);
+		atomicAdd(&A.counters->per_depth[A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1], (unsigned long long) cnt_trace);
+	}
+}
+
+// scene.root->intersect for arbitrary rays (parity tap + ptx_primary_hits)
+struct IntersectArgs {
+	DevScene S;
+	DevCamera cam;
+	const float* o;
+	const float* d;   // NULL => primary rays of sample `sample`
+	long long n;
+	unsigned sample;
+	int32_t* prim;
+	float* t;
+	float* pos;
+	float* nrm;
+	float* rdir;
+};
+__global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
+	__shared__ int lds_stack[kStack * kBlock];
+	int* stk = lds_stack + threadIdx.x;
+	for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < A.n; i += (long long) gridDim.x * kBlock) {
+		f3 o, d;
+		if (A.d) {
+			o = ld3(A.o + 3 * i);
+			d = ld3(A.d + 3 * i);
+		} else {
+			make_primary(A.cam, (unsigned) i, A.sample, o, d);
+		}
+		Hit h;
+		trace_closest(A.S, o, d, stk, h);
+		if (A.prim) A.prim[i] = h.id;
+		bool hit = h.id >= 0;
+		if (A.t) A.t[i] = hit ? h.t : 0.0f;
+		if (A.pos || A.nrm || A.rdir) {
+			Surface sf;
+			sf.pos = sf.n = sf.rdir = mk(0, 0, 0);
+			if (hit) sf = surface_of(A.S, o, d, h);
+			if (A.pos) { A.pos[3 * i] = sf.pos.x; A.pos[3 * i + 1] = sf.pos.y; A.pos[3 * i + 2] = sf.pos.z; }
+			if (A.nrm) { A.nrm[3 * i] = sf.n.x; A.nrm[3 * i + 1] = sf.n.y; A.nrm[3 * i + 2] = sf.n.z; }
+			if (A.rdir) { A.rdir[3 * i] = sf.rdir.x; A.rdir[3 * i + 1] = sf.rdir.y; A.rdir[3 * i + 2] = sf.rdir.z; }
+		}
+	}
+}
+
+// framework/renderer.cpp:86-89, :286-291 and ppmwriter.cpp:36-43
+__global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ accum, unsigned w, unsigned h, float inv_spp,
+                                                    float* __restrict__ color, uint8_t* __restrict__ rgb8) {
+	unsigned n = w * h;
+	for (unsigned p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+		unsigned x = p % w, y = p / w;
+		float c[3];
+#pragma unroll
+		for (int k = 0; k < 3; ++k) {
+			float v = accum[(size_t) p * 3 + k] * inv_spp;
+			v /= v + 1.0f;
+			c[k] = v;
+		}
+		if (color) {
+			color[(size_t) p * 3] = c[0];
+			color[(size_t) p * 3 + 1] = c[1];
+			color[(size_t) p * 3 + 2] = c[2];
+		}
+		if (rgb8) {
+			size_t q = 3 * ((size_t) w * (h - 1 - y) + x);
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				double v = 255.0 * (double) c[k];
+				v = (255.0 < v) ? 255.0 : v;  // std::min(255.0 * c, 255.0)
+				v = (0.0 < v) ? v : 0.0;      // std::max(0.0, .)
+				rgb8[q + k] = (uint8_t) (unsigned int) v;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+thread_local std::string g_error;
+
+PtxStatus fail(PtxStatus st, std::string msg) {
+	g_error = std::move(msg);
+	return st;
+}
+#define HIP_TRY(expr)                                                                                          \
+	do {                                                                                                       \
+		hipError_t e_ = (expr);                                                                                \
+		if (e_ != hipSuccess) return fail(PTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+bool finite16(const float* m) {
+	for (int i = 0; i < 16; ++i)
+		if (!std::isfinite(m[i])) return false;
+	return true;
+}
+bool is_identity(const float* m) {
+	for (int c = 0; c < 4; ++c)
+		for (int r = 0; r < 4; ++r)
+			if (m[c * 4 + r] != (c == r ? 1.0f : 0.0f)) return false;
+	return true;
+}
+
+}  // namespace
+
+struct PtxScene {
+	int device = 0;
+	DevScene dev{};
+	PtxCamera camera{};
+	std::vector<void*> allocs;
+	RayQueue q[2]{};
+	unsigned queue_capacity = 0;
+	unsigned* d_counts = nullptr;  // kMaxDepthSlots + 1 queue counters (padded to 1 KiB)
+	Counters* d_counters = nullptr;
+	bool branching = false;  // some material spawns two children per hit
+	bool bouncing = false;   // some material spawns any child
+	int n_prims = 0, n_frames = 0, n_nodes = 0, max_depth = 0, grid = 0;
+	uint64_t device_bytes = 0;
+
+	template <class T>
+	PtxStatus upload(std::vector<T> const& v, const T** out) {
+		void* p = nullptr;
+		size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256);
+		HIP_TRY(hipMalloc(&p, bytes));
+		allocs.push_back(p);
+		device_bytes += bytes;
+		HIP_TRY(hipMemset(p, 0, bytes));
+		if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+		*out = static_cast<const T*>(p);
+		return PTX_OK;
+	}
+};
+
+namespace {
+
+void camera_basis(const PtxCamera& c, const PtxRenderParams& rp, DevCamera& out) {
+	// framework/renderer.cpp:27-37.  tan is the double overload there; the quotient is
+	// formed in double and rounded once.
+	float fov_rad = c.fov_x / 180 * 3.14159265f;
+	float dist = (rp.width / 2.0f) / ::tan((double) (fov_rad / 2));
+	const float* dir = c.direction;
+	const float* up = c.up;
+	float u[3] = {dir[1] * up[2] - up[1] * dir[2], dir[2] * up[0] - up[2] * dir[0], dir[0] * up[1] - up[0] * dir[1]};
+	float v[3] = {u[1] * dir[2] - dir[1] * u[2], u[2] * dir[0] - dir[2] * u[0], u[0] * dir[1] - dir[0] * u[1]};
+	float m[16] = {u[0], u[1], u[2], 0, v[0], v[1], v[2], 0, -dir[0], -dir[1], -dir[2], 0, c.position[0], c.position[1], c.position[2], 1};
+	std::memcpy(out.m, m, sizeof m);
+	out.dist = dist;
+	out.aa_unit = 1.0f / rp.aa_steps;
+	out.half_w = rp.width * 0.5f;
+	out.half_h = rp.height * 0.5f;
+	out.width = rp.width;
+	out.height = rp.height;
+	out.aa_steps = rp.aa_steps;
+}
+
+PtxStatus check_params(const PtxRenderParams* p) {
+	if (!p) return fail(PTX_ERR_INVALID, "params is NULL");
+	if (p->width == 0 || p->height == 0 || p->aa_steps == 0) return fail(PTX_ERR_INVALID, "width, height and aa_steps must be positive");
+	if ((uint64_t) p->width * p->height > 0x7fffffffull / 3) return fail(PTX_ERR_INVALID, "image too large");
+	if ((uint64_t) p->aa_steps * p->aa_steps > 0xffffffffull) return fail(PTX_ERR_INVALID, "aa_steps too large");
+	if (p->sample_begin > p->sample_end || p->sample_end > p->aa_steps * p->aa_steps)
+		return fail(PTX_ERR_INVALID, "sample range outside [0, aa_steps^2]");
+	if (p->max_ray_bounces >= kMaxDepthSlots) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must be below 16");
+	return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptx_last_error(void) { return g_error.c_str(); }
+const char* ptx_version(void) { return "ptx 0.1 (gfx950)"; }
+
+int ptx_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_bytes, PtxScene** out) {
+	if (!D || !out) return fail(PTX_ERR_INVALID, "desc/out is NULL");
+	*out = nullptr;
+	if (D->n_frames < 1 || !D->frames) return fail(PTX_ERR_INVALID, "scene needs frame 0 (the root Composite)");
+	if (D->n_prims < 0 || D->n_materials < 0 || D->n_lights < 0) return fail(PTX_ERR_INVALID, "negative count");
+	if ((D->n_prims && !D->prims) || (D->n_materials && !D->materials) || (D->n_lights && !D->lights))
+		return fail(PTX_ERR_INVALID, "NULL array with non-zero count");
+	if (D->n_materials > 0xffff) return fail(PTX_ERR_UNSUPPORTED, "more than 65535 materials");
+	if (!is_identity(D->frames[0].world) || D->frames[0].parent != -1)
+		return fail(PTX_ERR_UNSUPPORTED, "frame 0 must be the untransformed root Composite");
+	for (int f = 1; f < D->n_frames; ++f)
+		if (D->frames[f].parent != 0) return fail(PTX_ERR_UNSUPPORTED, "only children of the root may carry a transform (frame.parent must be 0)");
+	int ndev = ptx_device_count();
+	if (ndev <= 0) return fail(PTX_ERR_DEVICE, "no HIP device: this library has no CPU path");
+	if (device < 0 || device >= ndev) return fail(PTX_ERR_INVALID, "device index out of range");
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+		return fail(PTX_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only");
+
+	std::unique_ptr<PtxScene> sc(new PtxScene);
+	sc->device = device;
+	sc->camera = D->camera;
+	sc->n_prims = D->n_prims;
+	sc->n_frames = D->n_frames;
+	sc->grid = prop.multiProcessorCount * 8;
+
+	// ---- materials, lights
+	std::vector<float4> mats((size_t) D->n_materials * 4);
+	for (int i = 0; i < D->n_materials; ++i) {
+		const PtxMaterial& m = D->materials[i];
+		mats[4 * i + 0] = make_float4(m.ka[0], m.ka[1], m.ka[2], m.kd[0]);
+		mats[4 * i + 1] = make_float4(m.kd[1], m.kd[2], m.ks[0], m.ks[1]);
+		mats[4 * i + 2] = make_float4(m.ks[2], m.m, m.glossy, m.opacity);
+		mats[4 * i + 3] = make_float4(m.ior, 0, 0, 0);
+		bool refl = m.glossy > 0, refr = m.opacity < 1;
+		if (refl && refr) sc->branching = true;
+		if (refl || refr) sc->bouncing = true;
+	}
+	std::vector<float4> lights((size_t) D->n_lights * 2);
+	for (int i = 0; i < D->n_lights; ++i) {
+		lights[2 * i] = make_float4(D->lights[i].position[0], D->lights[i].position[1], D->lights[i].position[2], 0);
+		lights[2 * i + 1] = make_float4(D->lights[i].intensity[0], D->lights[i].intensity[1], D->lights[i].intensity[2], 0);
+	}
+
+	// ---- leaves: frame 0 leaves stay a list; every other frame's triangles go into a BVH.
+	// A leaf or frame whose transform holds a non-finite number can never be hit by the
+	// reference's sphere test and is dropped here for every kind.
+	std::vector<DevRootPrim> root_prims;
+	std::vector<float4> prim_info((size_t) std::max(D->n_prims, 1));
+	std::vector<std::vector<int>> frame_tris(D->n_frames);
+	std::vector<char> frame_ok(D->n_frames, 1);
+	for (int f = 1; f < D->n_frames; ++f) {
+		const PtxFrame& F = D->frames[f];
+		bool ok = finite16(F.world) && finite16(F.world_inv);
+		for (int k = 0; k < 3; ++k) ok = ok && !std::isnan(F.bounds_min[k]) && !std::isnan(F.bounds_max[k]);
+		frame_ok[f] = ok;
+	}
+	for (int i = 0; i < D->n_prims; ++i) {
+		const PtxPrim& P = D->prims[i];
+		if (P.kind < 0 || P.kind > 2) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": unknown kind");
+		if (P.frame < 0 || P.frame >= D->n_frames) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": frame out of range");
+		if (P.material < 0 || P.material >= D->n_materials) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": material out of range");
+		if (P.levels_in < 0 || P.levels_in > 255) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": levels_in out of range");
+		int packed = P.material | (P.levels_in << 16);
+		float pw;
+		std::memcpy(&pw, &packed, 4);
+		prim_info[i] = make_float4(P.normal[0], P.normal[1], P.normal[2], pw);
+		bool finite = finite16(P.world) && finite16(P.world_inv);
+		for (int k = 0; k < 9; ++k) finite = finite && std::isfinite(P.p[k]);
+		if (P.frame == 0) {
+			if (P.levels_in < 1) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": a root leaf sits under at least the root (levels_in >= 1)");
+			if (!finite) continue;
+			DevRootPrim R{};
+			std::memcpy(R.winv, P.world_inv, sizeof R.winv);
+			std::memcpy(R.w, P.world, sizeof R.w);
+			std::memcpy(R.p, P.p, sizeof R.p);
+			if (P.kind == PTX_TRIANGLE)
+				for (int k = 0; k < 3; ++k) {
+					R.p[3 + k] = P.p[3 + k] - P.p[k];  // e1 = v1 - v0, framework/triangle.cpp:58
+					R.p[6 + k] = P.p[6 + k] - P.p[k];  // e2 = v2 - v0, :59
+				}
+			std::memcpy(R.n, P.normal, sizeof R.n);
+			R.kind = P.kind;
+			R.id = i;
+			R.levels_in = P.levels_in;
+			R.material = P.material;
+			root_prims.push_back(R);
+		} else {
+			if (P.kind != PTX_TRIANGLE) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": only triangles may live inside a mesh frame");
+			if (!is_identity(P.world)) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": a mesh triangle must not carry its own transform");
+			if (finite && frame_ok[P.frame]) frame_tris[P.frame].push_back(i);
+		}
+	}
+	std::vector<DevFrame> frames(D->n_frames);
+	std::vector<ptx::BvhNode> nodes;
+	std::vector<float4> tris;
+	for (int f = 1; f < D->n_frames; ++f) {
+		const PtxFrame& F = D->frames[f];
+		DevFrame& G = frames[f];
+		std::memcpy(G.winv, F.world_inv, sizeof G.winv);
+		std::memcpy(G.w, F.world, sizeof G.w);
+		std::memcpy(G.bmin, F.bounds_min, sizeof G.bmin);
+		std::memcpy(G.bmax, F.bounds_max, sizeof G.bmax);
+		G.levels_up = F.levels_up;
+		if (F.levels_up < 1 || F.levels_up > 255) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": levels_up out of range");
+		auto const& ids = frame_tris[f];
+		G.has_prims = !ids.empty();
+		if (ids.empty()) continue;
+		std::vector<ptx::Aabb> boxes(ids.size());
+		for (size_t k = 0; k < ids.size(); ++k) {
+			const float* p = D->prims[ids[k]].p;
+			for (int a = 0; a < 3; ++a) {
+				boxes[k].lo[a] = std::min(p[a], std::min(p[3 + a], p[6 + a]));
+				boxes[k].hi[a] = std::max(p[a], std::max(p[3 + a], p[6 + a]));
+			}
+		}
+		ptx::Bvh bvh = ptx::build_bvh(boxes);
+		if (bvh.max_depth > kStack) return fail(PTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+		sc->max_depth = std::max(sc->max_depth, bvh.max_depth);
+		G.bvh_root = bvh.root_ref;
+		G.node_base = (int32_t) nodes.size() * 4;
+		G.tri_base = (int32_t) tris.size();
+		nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+		for (int32_t k : bvh.order) {
+			int id = ids[k];
+			const float* p = D->prims[id].p;
+			float e1[3], e2[3];
+			for (int a = 0; a < 3; ++a) {
+				e1[a] = p[3 + a] - p[a];
+				e2[a] = p[6 + a] - p[a];
+			}
+			float idf;
+			std::memcpy(&idf, &id, 4);
+			tris.push_back(make_float4(p[0], p[1], p[2], e1[0]));
+			tris.push_back(make_float4(e1[1], e1[2], e2[0], e2[1]));
+			tris.push_back(make_float4(e2[2], idf, 0, 0));
+		}
+	}
+	sc->n_nodes = (int) nodes.size();
+
+	PtxStatus st;
+	DevScene& S = sc->dev;
+	if ((st = sc->upload(root_prims, &S.root_prims)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(frames, &S.frames)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	{
+		const ptx::BvhNode* dn = nullptr;
+		if ((st = sc->upload(nodes, &dn)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+		S.nodes = reinterpret_cast<const float4*>(dn);
+	}
+	if ((st = sc->upload(tris, &S.tris)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(prim_info, &S.prim_info)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(mats, &S.materials)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(lights, &S.lights)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	S.n_root_prims = (int) root_prims.size();
+	S.n_frames = D->n_frames;
+	S.n_lights = D->n_lights;
+	S.n_prims = D->n_prims;
+	std::memcpy(S.ambient, D->ambient, sizeof S.ambient);
+	std::memcpy(S.root_min, D->frames[0].bounds_min, sizeof S.root_min);
+	std::memcpy(S.root_max, D->frames[0].bounds_max, sizeof S.root_max);
+
+	// ---- ray queues: two ping-pong queues of `queue_capacity` rays (48 B each)
+	if (queue_bytes == 0) queue_bytes = 4ull << 30;
+	uint64_t cap = queue_bytes / 2 / 48;
+	cap = std::min<uint64_t>(cap, 1ull << 30);
+	cap = std::max<uint64_t>(cap, 1ull << 16);
+	cap &= ~63ull;
+	sc->queue_capacity = (unsigned) cap;
+	for (int k = 0; k < 2; ++k) {
+		void* p = nullptr;
+		hipError_t e = hipMalloc(&p, cap * 48);
+		if (e != hipSuccess) {
+			ptx_scene_destroy(sc.release());
+			return fail(PTX_ERR_NOMEM, std::string("ray queue allocation failed: ") + hipGetErrorString(e));
+		}
+		sc->allocs.push_back(p);
+		sc->device_bytes += cap * 48;
+		sc->q[k].a = static_cast<float4*>(p);
+		sc->q[k].b = sc->q[k].a + cap;
+		sc->q[k].c = sc->q[k].b + cap;
+	}
+	{
+		void* p = nullptr;
+		if (hipMalloc(&p, 1024) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
+		sc->allocs.push_back(p);
+		sc->d_counts = static_cast<unsigned*>(p);
+		if (hipMalloc(&p, 1024) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
+		sc->allocs.push_back(p);
+		sc->d_counters = static_cast<Counters*>(p);
+		static_assert(sizeof(Counters) <= 1024, "counter block");
+	}
+	*out = sc.release();
+	return PTX_OK;
+}
+
+void ptx_scene_destroy(PtxScene* scene) {
+	if (!scene) return;
+	(void) hipSetDevice(scene->device);
+	for (void* p : scene->allocs) (void) hipFree(p);
+	delete scene;
+}
+
+PtxStatus ptx_scene_info(const PtxScene* sc, int32_t* n_frames, int32_t* n_prims, int32_t* n_bvh_nodes, int32_t* max_bvh_depth,
+                         uint64_t* device_bytes) {
+	if (!sc) return fail(PTX_ERR_INVALID, "scene is NULL");
+	if (n_frames) *n_frames = sc->n_frames;
+	if (n_prims) *n_prims = sc->n_prims;
+	if (n_bvh_nodes) *n_bvh_nodes = sc->n_nodes;
+	if (max_bvh_depth) *max_bvh_depth = sc->max_depth;
+	if (device_bytes) *device_bytes = sc->device_bytes;
+	return PTX_OK;
+}
+
+PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* d_accum, void* stream_, int check_overflow,
+                                PtxStats* stats) {
+	if (!sc || !d_accum) return fail(PTX_ERR_INVALID, "scene/d_accum is NULL");
+	PtxStatus st = check_params(rp);
+	if (st != PTX_OK) return st;
+	hipStream_t stream = static_cast<hipStream_t>(stream_);
+	HIP_TRY(hipSetDevice(sc->device));
+
+	BounceArgs A{};
+	A.S = sc->dev;
+	camera_basis(sc->camera, *rp, A.cam);
+	A.accum = d_accum;
+	A.counters = sc->d_counters;
+	A.out_capacity = sc->queue_capacity;
+	const unsigned ns = rp->sample_end - rp->sample_begin;
+	A.ns = ns;
+	A.s0 = rp->sample_begin;
+	const uint64_t total = (uint64_t) rp->width * rp->height * ns;
+	const unsigned max_depth = sc->bouncing ? rp->max_ray_bounces : 0;  // no material spawns rays: depth 0 only
+
+	// Primary batch: small enough that the ray tree cannot outgrow a queue even if every hit
+	// spawns the most children its scene's materials allow.
+	uint64_t batch = sc->queue_capacity;
+	if (sc->branching) batch = std::max<uint64_t>(sc->queue_capacity >> std::min(max_depth, 31u), 1u << 16);
+	batch = std::min<uint64_t>(batch, 1ull << 30);
+	batch &= ~63ull;
+
+	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 1024, stream));
+	uint64_t launches = 0;
+	for (uint64_t first = 0; first < total; first += batch) {
+		unsigned cnt = (unsigned) std::min<uint64_t>(batch, total - first);
+		HIP_TRY(hipMemsetAsync(sc->d_counts, 0, 1024, stream));
+		A.first = first;
+		A.batch = cnt;
+		A.depth = 0;
+		A.last_depth = (max_depth == 0);
+		A.in = sc->q[1];
+		A.out = sc->q[0];
+		A.in_count = nullptr;
+		A.out_count = sc->d_counts + 1;
+		unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
+		hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
+		++launches;
+		for (unsigned d = 1; d <= max_depth; ++d) {
+			A.depth = d;
+			A.last_depth = (d == max_depth);
+			A.in = sc->q[(d - 1) & 1];
+			A.out = sc->q[d & 1];
+			A.in_count = sc->d_counts + d;
+			A.out_count = sc->d_counts + d + 1;
+			hipLaunchKernelGGL(k_bounce<false>, dim3(sc->grid), dim3(kBlock), 0, stream, A);
+			++launches;
+		}
+	}
+	HIP_TRY(hipGetLastError());
+	if (check_overflow || stats) {
+		Counters c;
+		HIP_TRY(hipMemcpyAsync(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		if (stats) {
+			std::memset(stats, 0, sizeof *stats);
+			stats->samples = total;
+			stats->trace_rays = c.trace_rays;
+			stats->shadow_rays = c.shadow_rays;
+			stats->shaded_hits = c.shaded_hits;
+			stats->launches = launches;
+			for (int k = 0; k < kMaxDepthSlots; ++k) stats->per_depth_rays[k] = c.per_depth[k];
+		}
+		if (c.overflow)
+			return fail(PTX_ERR_OVERFLOW, "a ray queue overflowed (" + std::to_string(c.overflow) +
+			                                  " waves dropped rays); the image is incomplete: raise queue_bytes in ptx_scene_create");
+	}
+	return PTX_OK;
+}
+
+PtxStatus ptx_resolve(int device, const float* d_accum, uint32_t w, uint32_t h, uint32_t spp, float* d_color, uint8_t* d_rgb8,
+                      void* stream_) {
+	if (!d_accum || w == 0 || h == 0 || spp == 0) return fail(PTX_ERR_INVALID, "bad resolve arguments");
+	HIP_TRY(hipSetDevice(device));
+	hipStream_t stream = static_cast<hipStream_t>(stream_);
+	// framework/renderer.cpp:86: traced_color *= 1.0f / (aa_steps_ * aa_steps_)
+	float inv_spp = 1.0f / (float) spp;
+	unsigned n = w * h;
+	unsigned grid = std::min<unsigned>((n + kBlock - 1) / kBlock, 4096u);
+	hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, stream, d_accum, w, h, inv_spp, d_color, d_rgb8);
+	HIP_TRY(hipGetLastError());
+	return PTX_OK;
+}
+
+PtxStatus ptx_render_image(PtxScene* sc, const PtxRenderParams* rp, float* color, uint8_t* rgb8, double* seconds, PtxStats* stats) {
+	if (!sc) return fail(PTX_ERR_INVALID, "scene is NULL");
+	PtxStatus st = check_params(rp);
+	if (st != PTX_OK) return st;
+	HIP_TRY(hipSetDevice(sc->device));
+	size_t npix = (size_t) rp->width * rp->height;
+	float* d_accum = nullptr;
+	float* d_color = nullptr;
+	uint8_t* d_rgb = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	auto cleanup = [&]() {
+		if (d_accum) (void) hipFree(d_accum);
+		if (d_color) (void) hipFree(d_color);
+		if (d_rgb) (void) hipFree(d_rgb);
+		if (e0) (void) hipEventDestroy(e0);
+		if (e1) (void) hipEventDestroy(e1);
+	};
+#define TRY_C(expr)                                                                                  \
+	do {                                                                                             \
+		hipError_t e_ = (expr);                                                                      \
+		if (e_ != hipSuccess) {                                                                      \
+			cleanup();                                                                               \
+			return fail(PTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+		}                                                                                            \
+	} while (0)
+	TRY_C(hipMalloc(&d_accum, npix * 3 * sizeof(float)));
+	TRY_C(hipMalloc(&d_color, npix * 3 * sizeof(float)));
+	TRY_C(hipMalloc(&d_rgb, npix * 3));
+	TRY_C(hipEventCreate(&e0));
+	TRY_C(hipEventCreate(&e1));
+	TRY_C(hipMemsetAsync(d_accum, 0, npix * 3 * sizeof(float), nullptr));
+	TRY_C(hipEventRecord(e0, nullptr));
+	PtxRenderParams full = *rp;
+	st = ptx_render_accumulate(sc, &full, d_accum, nullptr, 1, stats);
+	if (st != PTX_OK) { cleanup(); return st; }
+	unsigned spp = rp->sample_end - rp->sample_begin;
+	// a partial sample range is averaged over the WHOLE grid only by the caller that sums
+	// the ranges; here the image is what this range alone gives
+	st = ptx_resolve(sc->device, d_accum, rp->width, rp->height, spp ? spp : 1, d_color, d_rgb, nullptr);
+	if (st != PTX_OK) { cleanup(); return st; }
+	TRY_C(hipEventRecord(e1, nullptr));
+	TRY_C(hipEventSynchronize(e1));
+	if (seconds) {
+		float ms = 0;
+		TRY_C(hipEventElapsedTime(&ms, e0, e1));
+		*seconds = ms * 1e-3;
+	}
+	if (color) TRY_C(hipMemcpy(color, d_color, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+	if (rgb8) TRY_C(hipMemcpy(rgb8, d_rgb, npix * 3, hipMemcpyDeviceToHost));
+	cleanup();
+#undef TRY_C
+	return PTX_OK;
+}
+
+static PtxStatus run_intersect(PtxScene* sc, IntersectArgs& A, int64_t n, int32_t* prim, float* t, float* pos, float* nrm, float* rdir,
+                               const float* o, const float* d) {
+	std::vector<void*> tmp;
+	auto cleanup = [&]() {
+		for (void* p : tmp) (void) hipFree(p);
+	};
+	auto dalloc = [&](size_t bytes, void** p) -> hipError_t {
+		hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
+		if (e == hipSuccess) tmp.push_back(*p);
+		return e;
+	};
+#define TRY_C(expr)                                                                         \
+	do {                                                                                    \
+		hipError_t e_ = (expr);                                                             \
+		if (e_ != hipSuccess) {                                                             \
+			cleanup();                                                                      \
+			return fail(PTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+		}                                                                                   \
+	} while (0)
+	void *d_o = nullptr, *d_d = nullptr, *d_prim = nullptr, *d_t = nullptr, *d_pos = nullptr, *d_nrm = nullptr, *d_rd = nullptr;
+	if (o) {
+		TRY_C(dalloc((size_t) n * 12, &d_o));
+		TRY_C(dalloc((size_t) n * 12, &d_d));
+		TRY_C(hipMemcpy(d_o, o, (size_t) n * 12, hipMemcpyHostToDevice));
+		TRY_C(hipMemcpy(d_d, d, (size_t) n * 12, hipMemcpyHostToDevice));
+	}
+	if (prim) TRY_C(dalloc((size_t) n * 4, &d_prim));
+	if (t) TRY_C(dalloc((size_t) n * 4, &d_t));
+	if (pos) TRY_C(dalloc((size_t) n * 12, &d_pos));
+	if (nrm) TRY_C(dalloc((size_t) n * 12, &d_nrm));
+	if (rdir) TRY_C(dalloc((size_t) n * 12, &d_rd));
+	A.S = sc->dev;
+	A.o = static_cast<const float*>(d_o);
+	A.d = static_cast<const float*>(d_d);
+	A.n = n;
+	A.prim = static_cast<int32_t*>(d_prim);
+	A.t = static_cast<float*>(d_t);
+	A.pos = static_cast<float*>(d_pos);
+	A.nrm = static_cast<float*>(d_nrm);
+	A.rdir = static_cast<float*>(d_rd);
+	unsigned grid = (unsigned) std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t) sc->grid);
+	if (grid == 0) grid = 1;
+	hipLaunchKernelGGL(k_intersect, dim3(grid), dim3(kBlock), 0, nullptr, A);
+	TRY_C(hipGetLastError());
+	TRY_C(hipDeviceSynchronize());
+	if (prim) TRY_C(hipMemcpy(prim, d_prim, (size_t) n * 4, hipMemcpyDeviceToHost));
+	if (t) TRY_C(hipMemcpy(t, d_t, (size_t) n * 4, hipMemcpyDeviceToHost));
+	if (pos) TRY_C(hipMemcpy(pos, d_pos, (size_t) n * 12, hipMemcpyDeviceToHost));
+	if (nrm) TRY_C(hipMemcpy(nrm, d_nrm, (size_t) n * 12, hipMemcpyDeviceToHost));
+	if (rdir) TRY_C(hipMemcpy(rdir, d_rd, (size_t) n * 12, hipMemcpyDeviceToHost));
+	cleanup();
+#undef TRY_C
+	return PTX_OK;
+}
+
+PtxStatus ptx_intersect(PtxScene* sc, int64_t n, const float* origins, const float* dirs, int32_t* prim, float* t, float* pos,
+                        float* normal, float* raydir) {
+	if (!sc) return fail(PTX_ERR_INVALID, "scene is NULL");
+	if (n < 0 || (n > 0 && (!origins || !dirs))) return fail(PTX_ERR_INVALID, "bad ray arrays");
+	if (n == 0) return PTX_OK;
+	HIP_TRY(hipSetDevice(sc->device));
+	IntersectArgs A{};
+	return run_intersect(sc, A, n, prim, t, pos, normal, raydir, origins, dirs);
+}
+
+PtxStatus ptx_primary_hits(PtxScene* sc, const PtxRenderParams* rp, uint32_t sample, int32_t* prim, float* t) {
+	if (!sc) return fail(PTX_ERR_INVALID, "scene is NULL");
+	PtxStatus st = check_params(rp);
+	if (st != PTX_OK) return st;
+	if (sample >= rp->aa_steps * rp->aa_steps) return fail(PTX_ERR_INVALID, "sample outside the aa grid");
+	HIP_TRY(hipSetDevice(sc->device));
+	IntersectArgs A{};
+	camera_basis(sc->camera, *rp, A.cam);
+	A.sample = sample;
+	return run_intersect(sc, A, (int64_t) rp->width * rp->height, prim, t, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+	if (!path || !rgb8) return fail(PTX_ERR_INVALID, "path/rgb8 is NULL");
+	FILE* f = std::fopen(path, "wb");
+	if (!f) return fail(PTX_ERR_INVALID, std::string("cannot open ") + path);
+	// framework/ppmwriter.cpp:61-73: header, then "<value> " with a newline after every 19th value
+	std::string s = "P3 " + std::to_string(w) + " " + std::to_string(h) + " 255 \n";
+	size_t n = (size_t) w * h * 3;
+	s.reserve(n * 4 + 64);
+	size_t pos = 1;
+	char buf[8];
+	for (size_t i = 0; i < n; ++i, ++pos) {
+		int len = std::snprintf(buf, sizeof buf, "%d ", (int) rgb8[i]);
+		s.append(buf, (size_t) len);
+		if (pos > 18) {
+			s.push_back('\n');
+			pos = 0;
+		}
+	}
+	bool ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
+	ok = (std::fclose(f) == 0) && ok;
+	return ok ? PTX_OK : fail(PTX_ERR_INVALID, std::string("short write to ") + path);
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Host-side BVH builder for one frame's triangles (replaces the role of the reference's
+// octree, framework/composite.cpp:120-161, as the acceleration structure; the octree's
+// effect on WHICH leaves exist and in WHAT order they win ties is carried by the
+// primitive ids, not by this tree).
+//
+// Layout produced (device format, see ptx.hip):
+//   node  = 4 x float4 (64 B): both children's boxes + both child references
+//           q0 = (lo0.x, lo0.y, lo0.z, hi0.x)  q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
+//           q2 = (lo1.z, hi1.x, hi1.y, hi1.z)  q3 = (bits(child0), bits(child1), 0, 0)
+//   child reference >= 0: node index (relative to the frame's first node)
+//                   <  0: leaf, v = ~ref, first item = v >> 3, item count = (v & 7) + 1
+//   order = the item permutation: leaf items [first, first+count) index into it.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace ptx {
+
+struct Aabb {
+	float lo[3], hi[3];
+};
+
+struct BvhNode {
+	float q[16];
+};
+
+struct Bvh {
+	std::vector<BvhNode> nodes;
+	std::vector<int32_t> order;
+	int32_t root_ref = -1;  // child reference of the whole tree
+	int32_t max_depth = 0;  // deepest leaf (root = 0); the traversal stack needs this many slots
+	bool empty = true;
+};
+
+constexpr int kBvhMaxLeaf = 4;
+constexpr int kBvhMaxDepth = 30;
+
+// boxes must be finite.  Deterministic (no threading, no RNG).
+Bvh build_bvh(std::vector<Aabb> const& boxes);
+
+}  // namespace ptx

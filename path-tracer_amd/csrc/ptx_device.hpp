@@ -1,0 +1,156 @@
+// Device-side arithmetic of the render path for gfx950, written so that every value the
+// reference computes per ray (hit distance, position, normal, local ray direction) comes
+// out with the same fp32 operation sequence: this translation unit is compiled with
+// -ffp-contract=off (no FMA contraction; the reference build has none), IEEE divide and
+// sqrt, and the min/max selections are the C++ ternaries of std::min/std::max/glm::min,
+// not fminf/fmaxf (which differ on NaN).  The ONLY place that may round differently is
+// the BVH node test (bvh_slab), which is a conservative filter and never produces a value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptxd {
+
+constexpr float kEps = 0.001f;  // EPSILON of framework/{renderer,sphere,box,triangle}.cpp
+constexpr float kInf = __builtin_huge_valf();
+
+struct f3 {
+	float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ f3 cmul(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }  // Color * Color
+// glm detail/func_geometric.inl:61-68, :212-224, :104-110, :252-261
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+__device__ __forceinline__ float length(f3 v) { return __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+__device__ __forceinline__ f3 normalize(f3 v) {
+	float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
+	return v * (1.0f / __builtin_sqrtf(sqr));
+}
+__device__ __forceinline__ bool any_nonzero(f3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
+
+// std::min / std::max semantics (b < a ? b : a  /  a < b ? b : a), framework/box.cpp:123-147
+__device__ __forceinline__ float smin(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float smax(float a, float b) { return a < b ? b : a; }
+
+// glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*w), detail/type_mat4x4.inl:676-687.
+// M is column-major (element [c*4+r]).  transform_vec of framework/shape.cpp:46-48.
+__device__ __forceinline__ f3 xform_point(const float* __restrict__ M, f3 v) {
+	return {(M[0] * v.x + M[4] * v.y) + (M[8] * v.z + M[12] * 1.0f), (M[1] * v.x + M[5] * v.y) + (M[9] * v.z + M[13] * 1.0f),
+	        (M[2] * v.x + M[6] * v.y) + (M[10] * v.z + M[14] * 1.0f)};
+}
+__device__ __forceinline__ f3 xform_dir(const float* __restrict__ M, f3 v) {
+	return {(M[0] * v.x + M[4] * v.y) + (M[8] * v.z + M[12] * 0.0f), (M[1] * v.x + M[5] * v.y) + (M[9] * v.z + M[13] * 0.0f),
+	        (M[2] * v.x + M[6] * v.y) + (M[10] * v.z + M[14] * 0.0f)};
+}
+
+// Box::intersect(Ray, float&) of framework/box.cpp:105-165 on an already-local ray.
+__device__ __forceinline__ bool box_slab(f3 lo, f3 hi, f3 o, f3 d, float& t) {
+	float t_min = -kInf, t_max = kInf;
+	if (0.0f == d.x) {
+		if (o.x < lo.x || o.x > hi.x) return false;
+	} else {
+		float inv = 1.0f / d.x;
+		float t1 = (lo.x - o.x) * inv, t2 = (hi.x - o.x) * inv;
+		t_min = smax(t_min, smin(t1, t2));
+		t_max = smin(t_max, smax(t1, t2));
+	}
+	if (0.0f == d.y) {
+		if (o.y < lo.y || o.y > hi.y) return false;
+	} else {
+		float inv = 1.0f / d.y;
+		float t1 = (lo.y - o.y) * inv, t2 = (hi.y - o.y) * inv;
+		t_min = smax(t_min, smin(t1, t2));
+		t_max = smin(t_max, smax(t1, t2));
+	}
+	if (0.0f == d.z) {
+		if (o.z < lo.z || o.z > hi.z) return false;
+	} else {
+		float inv = 1.0f / d.z;
+		float t1 = (lo.z - o.z) * inv, t2 = (hi.z - o.z) * inv;
+		t_min = smax(t_min, smin(t1, t2));
+		t_max = smin(t_max, smax(t1, t2));
+	}
+	if (t_max < t_min) return false;
+	if (t_min > 0.0f) t = t_min;
+	else if (t_max > 0.0f) t = t_max;
+	else return false;
+	t -= kEps;
+	return true;
+}
+
+// Box::surface_normal, framework/box.cpp:167-182
+__device__ __forceinline__ f3 box_face_normal(f3 lo, f3 hi, f3 p) {
+	if (p.x <= lo.x + kEps * 2) return {-1, 0, 0};
+	else if (p.y <= lo.y + kEps * 2) return {0, -1, 0};
+	else if (p.z <= lo.z + kEps * 2) return {0, 0, -1};
+	else if (p.x >= hi.x - kEps * 2) return {1, 0, 0};
+	else if (p.y >= hi.y - kEps * 2) return {0, 1, 0};
+	else if (p.z >= hi.z - kEps * 2) return {0, 0, 1};
+	return {0, 0, 0};
+}
+
+// Sphere::intersect up to `t` (framework/sphere.cpp:35-46 + glm gtx/intersect.inl:152-170);
+// (o, d) is the ray already in the sphere's local space.
+__device__ __forceinline__ bool sphere_t(f3 c, float radius, f3 o, f3 d, float& t) {
+	const float feps = 1.1920928955078125e-07f;  // std::numeric_limits<float>::epsilon()
+	f3 dn = normalize(d);
+	float r2 = radius * radius;
+	f3 diff = c - o;
+	float t0 = dot(diff, dn);
+	float dsq = dot(diff, diff) - t0 * t0;
+	if (dsq > r2) return false;
+	float t1 = __builtin_sqrtf(r2 - dsq);
+	float tt = t0 > t1 + feps ? t0 - t1 : t0 + t1;
+	if (!(tt > feps)) return false;
+	tt /= length(d);
+	tt -= kEps;
+	t = tt;
+	return true;
+}
+
+// Triangle::intersect up to `t` (framework/triangle.cpp:56-85) with e1 = v1 - v0 and
+// e2 = v2 - v0 formed beforehand (same single fp32 subtraction the reference does per call).
+__device__ __forceinline__ bool tri_t(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float& t) {
+	f3 p = cross(d, e2);
+	float det = dot(e1, p);
+	if (det < kEps && det > -kEps) return false;
+	float inv_det = 1.0f / det;
+	f3 tv = o - v0;
+	float u = dot(tv, p) * inv_det;
+	if (u < 0.0f || u > 1.0f) return false;
+	f3 q = cross(tv, e1);
+	float v = dot(d, q) * inv_det;
+	if (v < 0.0f || u + v > 1.0f) return false;
+	float tt = dot(e2, q) * inv_det;
+	if (tt < kEps) return false;
+	t = tt - kEps;
+	return true;
+}
+
+// Renderer::schlick_reflection_ratio, framework/renderer.cpp:252-276
+__device__ __forceinline__ float schlick(f3 rd, f3 n, float ior) {
+	float n1 = 1.0f, n2 = ior;
+	float cos_in = -dot(n, rd);
+	if (cos_in < 0.0f) {
+		float tmp = n1;
+		n1 = n2;
+		n2 = tmp;
+	}
+	if (n1 > n2) {
+		float eta = n1 / n2;
+		float s2 = eta * eta * (1.0f - cos_in * cos_in);
+		if (s2 >= 1.0f) return 1.0f;
+		cos_in = __builtin_sqrtf(1.0f - s2);
+	}
+	float r0 = (1.0f - ior) / (1.0f + ior);
+	r0 *= r0;
+	float f = 1.0f - cos_in;
+	return r0 + (1.0f - r0) * f * f * f * f * f;
+}
+
+}  // namespace ptxd
