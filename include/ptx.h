@@ -140,7 +140,14 @@ typedef struct PtxStats {
 	uint64_t shadow_rays;  /* any-hit queries                                        */
 	uint64_t shaded_hits;  /* hits that were shaded                                  */
 	uint64_t launches;     /* bounce-kernel launches                                 */
-	uint64_t per_depth_rays[16];
+	uint64_t per_depth_rays[16];    /* closest-hit queries per ray-tree depth          */
+	uint64_t per_depth_shadow[16];  /* any-hit queries issued at that depth            */
+	uint64_t per_depth_hits[16];    /* shaded hits at that depth                       */
+	/* filled only while profiling is on (ptx_scene_set_profiling): device time of the
+	 * bounce kernel per depth, from HIP events recorded around every launch on the
+	 * caller's stream, and the number of launches timed */
+	double per_depth_ms[16];
+	uint64_t per_depth_launches[16];
 } PtxStats;
 
 const char* ptx_last_error(void);
@@ -201,6 +208,14 @@ PtxStatus ptx_primary_hits(PtxScene* scene, const PtxRenderParams* params, uint3
 
 /* PpmWriter::save (framework/ppmwriter.cpp:55-76): ASCII P3 from the flipped rgb8 rows. */
 PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
+/*
+ * Profiling on: ptx_render_accumulate brackets every bounce-kernel launch with a pair of
+ * HIP events on the caller's stream and reports per-depth kernel time in PtxStats (which
+ * then must be requested).  Off by default.  No counterpart in the reference, whose only
+ * timing is a wall clock around render() (framework/renderer.cpp:43,54-56).
+ */
+PtxStatus ptx_scene_set_profiling(PtxScene* scene, int enable);
 
 /* Introspection for tests and DESIGN numbers: BVH node / leaf-triangle counts, depth. */
 PtxStatus ptx_scene_info(const PtxScene* scene, int32_t* n_frames, int32_t* n_prims, int32_t* n_bvh_nodes,

@@ -26,6 +26,7 @@ STATUS_NAMES = {0: "PTX_OK", 1: "PTX_ERR_INVALID", 2: "PTX_ERR_UNSUPPORTED", 3: 
 PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
     "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_scene_info",
+    "ptx_scene_set_profiling",
 ]
 
 
@@ -71,11 +72,14 @@ class PtxRenderParams(C.Structure):
 
 class PtxStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("trace_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
-                ("launches", C.c_uint64), ("per_depth_rays", C.c_uint64 * 16)]
+                ("launches", C.c_uint64), ("per_depth_rays", C.c_uint64 * 16), ("per_depth_shadow", C.c_uint64 * 16),
+                ("per_depth_hits", C.c_uint64 * 16), ("per_depth_ms", C.c_double * 16), ("per_depth_launches", C.c_uint64 * 16)]
 
     def as_dict(self):
         return dict(samples=self.samples, trace_rays=self.trace_rays, shadow_rays=self.shadow_rays, shaded_hits=self.shaded_hits,
-                    launches=self.launches, per_depth_rays=list(self.per_depth_rays))
+                    launches=self.launches, per_depth_rays=list(self.per_depth_rays), per_depth_shadow=list(self.per_depth_shadow),
+                    per_depth_hits=list(self.per_depth_hits), per_depth_ms=list(self.per_depth_ms),
+                    per_depth_launches=list(self.per_depth_launches))
 
 
 _libs = {}
@@ -107,6 +111,7 @@ def ptx_lib():
     L.ptx_intersect.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.ptx_primary_hits.argtypes = [vp, C.POINTER(PtxRenderParams), C.c_uint32, vp, vp]
     L.ptx_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.ptx_scene_set_profiling.argtypes = [vp, C.c_int]
     L.ptx_scene_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L._typed = True
     return L
@@ -217,6 +222,9 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+    def set_profiling(self, enable=True):
+        _check(self.L.ptx_scene_set_profiling(self.handle, int(enable)))
 
     def info(self):
         a, b, c, d, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()

@@ -39,7 +39,10 @@ namespace {
 constexpr int kBlock = 256;  // 4 wave64 per workgroup
 constexpr int kStack = 32;   // per-lane BVH stack slots in LDS (>= ptx::kBvhMaxDepth)
 static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
-constexpr int kMaxDepthSlots = 16;
+constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
+constexpr unsigned kMaxBounces = 63;
+constexpr unsigned kCountStride = 64;           // one queue counter per 256-B line
+constexpr size_t kCountBytes = (kMaxBounces + 2) * kCountStride * sizeof(unsigned);
 
 // ---------------------------------------------------------------------------
 // device scene
@@ -99,6 +102,8 @@ struct Hit {
 struct Counters {  // cumulative over one ptx_render_accumulate
 	unsigned long long trace_rays, shadow_rays, shaded_hits, overflow;
 	unsigned long long per_depth[kMaxDepthSlots];
+	unsigned long long per_depth_shadow[kMaxDepthSlots];
+	unsigned long long per_depth_hits[kMaxDepthSlots];
 };
 
 __device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
@@ -125,6 +130,11 @@ __device__ __forceinline__ void bvh_slab2(float4 q0, float4 q1, float4 q2, f3 in
 	h1 = tn1 <= tf1;
 }
 
+__device__ __forceinline__ float bvh_rcp(float d) {
+	float r = 1.0f / d;
+	return fabsf(r) > 1e18f ? copysignf(1e18f, r) : r;
+}
+
 // far limit for node culling given the best reported distance (reported = raw - kEps)
 __device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0f * kEps + 1e-5f * fabsf(best_t)); }
 
@@ -133,7 +143,11 @@ __device__ __forceinline__ bool bvh_walk(const DevScene& S, const DevFrame& F, i
                                          float range) {
 	const float4* __restrict__ nodes = S.nodes + F.node_base;
 	const float4* __restrict__ tris = S.tris + F.tri_base;
-	f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+	// Reciprocal direction for the node tests only.  A zero (or denormal-small) component
+	// would give inf and then inf - inf = NaN inside the fused slab test, which fminf/fmaxf
+	// would read as "no constraint on the wrong side"; a huge finite reciprocal keeps the
+	// test ordered, and the padding of the node boxes covers its rounding.
+	f3 inv = {bvh_rcp(d.x), bvh_rcp(d.y), bvh_rcp(d.z)};
 	f3 noi = {-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)};
 	int sp = 0;
 	int cur = F.bvh_root;
@@ -471,11 +485,13 @@ struct BounceArgs {
 	DevScene S;
 	DevCamera cam;
 	RayQueue in, out;
-	const unsigned* in_count;  // rays in `in` (depth > 0)
+	const unsigned* in_count;  // rays in `in` (depth > 0), read on the device; NULL => `batch` rays from `in_offset`
 	unsigned* out_count;       // rays appended to `out`
 	unsigned out_capacity;
+	unsigned in_capacity;
+	unsigned in_offset;
 	unsigned long long first;  // depth 0: first linear sample index of the batch
-	unsigned batch;            // depth 0: samples in the batch
+	unsigned batch;            // depth 0: samples in the batch; depth > 0 with in_count == NULL: rays to take
 	unsigned ns, s0;           // samples per pixel in this render's range, first sample
 	unsigned depth;
 	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned n = PRIMARY ? A.batch : min(*A.in_count, A.out_capacity);  // `in` has the same capacity as `out`
+	const unsigned n = (PRIMARY || !A.in_count) ? A.batch : min(*A.in_count, A.in_capacity);
 	const unsigned waves_per_block = kBlock / 64;
 	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * waves_per_block;
@@ -506,7 +522,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
 				unsigned s = A.s0 + (unsigned) (li - (unsigned long long) pix * A.ns);
 				make_primary(A.cam, pix, s, o, d);
 			} else {
-				float4 a = A.in.a[i], b = A.in.b[i], c = A.in.c[i];
+				const unsigned j = A.in_offset + i;
+				float4 a = A.in.a[j], b = A.in.b[j], c = A.in.c[j];
 				o = mk(a.x, a.y, a.z);
 				d = mk(a.w, b.x, b.y);
 				w = mk(b.z, b.w, c.x);
@@ -565,7 +582,10 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
 		atomicAdd(&A.counters->trace_rays, (unsigned long long) cnt_trace);
 		atomicAdd(&A.counters->shadow_rays, (unsigned long long) cnt_shadow);
 		atomicAdd(&A.counters->shaded_hits, (unsigned long long) cnt_hits);
-		atomicAdd(&A.counters->per_depth[A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1], (unsigned long long) cnt_trace);
+		unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
+		atomicAdd(&A.counters->per_depth[slot], (unsigned long long) cnt_trace);
+		atomicAdd(&A.counters->per_depth_shadow[slot], (unsigned long long) cnt_shadow);
+		atomicAdd(&A.counters->per_depth_hits[slot], (unsigned long long) cnt_hits);
 	}
 }
 
@@ -675,12 +695,15 @@ struct PtxScene {
 	DevScene dev{};
 	PtxCamera camera{};
 	std::vector<void*> allocs;
-	RayQueue q[2]{};
-	unsigned queue_capacity = 0;
-	unsigned* d_counts = nullptr;  // kMaxDepthSlots + 1 queue counters (padded to 1 KiB)
+	float4* qmem = nullptr;  // one block of ray records (48 B each), cut into queues per render
+	uint64_t qrays = 0;      // ray slots in qmem
+	unsigned* d_counts = nullptr;  // queue counters, one per depth, each on its own 256-B line
 	Counters* d_counters = nullptr;
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
+	bool profiling = false;
+	std::vector<hipEvent_t> events;      // pairs, reused from call to call
+	std::vector<unsigned> event_depth;   // depth of pair k
 	int n_prims = 0, n_frames = 0, n_nodes = 0, max_depth = 0, grid = 0;
 	uint64_t device_bytes = 0;
 
@@ -727,7 +750,7 @@ PtxStatus check_params(const PtxRenderParams* p) {
 	if ((uint64_t) p->aa_steps * p->aa_steps > 0xffffffffull) return fail(PTX_ERR_INVALID, "aa_steps too large");
 	if (p->sample_begin > p->sample_end || p->sample_end > p->aa_steps * p->aa_steps)
 		return fail(PTX_ERR_INVALID, "sample range outside [0, aa_steps^2]");
-	if (p->max_ray_bounces >= kMaxDepthSlots) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must be below 16");
+	if (p->max_ray_bounces > kMaxBounces) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must not exceed 63");
 	return PTX_OK;
 }
 
@@ -907,14 +930,14 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(S.root_min, D->frames[0].bounds_min, sizeof S.root_min);
 	std::memcpy(S.root_max, D->frames[0].bounds_max, sizeof S.root_max);
 
-	// ---- ray queues: two ping-pong queues of `queue_capacity` rays (48 B each)
+	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
 	if (queue_bytes == 0) queue_bytes = 4ull << 30;
-	uint64_t cap = queue_bytes / 2 / 48;
-	cap = std::min<uint64_t>(cap, 1ull << 30);
-	cap = std::max<uint64_t>(cap, 1ull << 16);
-	cap &= ~63ull;
-	sc->queue_capacity = (unsigned) cap;
-	for (int k = 0; k < 2; ++k) {
+	uint64_t cap = queue_bytes / 48;
+	cap = std::min<uint64_t>(cap, 1ull << 31);
+	cap = std::max<uint64_t>(cap, 1ull << 17);
+	cap &= ~127ull;
+	sc->qrays = cap;
+	{
 		void* p = nullptr;
 		hipError_t e = hipMalloc(&p, cap * 48);
 		if (e != hipSuccess) {
@@ -923,13 +946,11 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		}
 		sc->allocs.push_back(p);
 		sc->device_bytes += cap * 48;
-		sc->q[k].a = static_cast<float4*>(p);
-		sc->q[k].b = sc->q[k].a + cap;
-		sc->q[k].c = sc->q[k].b + cap;
+		sc->qmem = static_cast<float4*>(p);
 	}
 	{
 		void* p = nullptr;
-		if (hipMalloc(&p, 1024) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
+		if (hipMalloc(&p, kCountBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
 		sc->d_counts = static_cast<unsigned*>(p);
 		if (hipMalloc(&p, 1024) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
@@ -941,9 +962,16 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	return PTX_OK;
 }
 
+PtxStatus ptx_scene_set_profiling(PtxScene* scene, int enable) {
+	if (!scene) return fail(PTX_ERR_INVALID, "scene is NULL");
+	scene->profiling = enable != 0;
+	return PTX_OK;
+}
+
 void ptx_scene_destroy(PtxScene* scene) {
 	if (!scene) return;
 	(void) hipSetDevice(scene->device);
+	for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
 	for (void* p : scene->allocs) (void) hipFree(p);
 	delete scene;
 }
@@ -972,46 +1000,127 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	camera_basis(sc->camera, *rp, A.cam);
 	A.accum = d_accum;
 	A.counters = sc->d_counters;
-	A.out_capacity = sc->queue_capacity;
 	const unsigned ns = rp->sample_end - rp->sample_begin;
 	A.ns = ns;
 	A.s0 = rp->sample_begin;
 	const uint64_t total = (uint64_t) rp->width * rp->height * ns;
 	const unsigned max_depth = sc->bouncing ? rp->max_ray_bounces : 0;  // no material spawns rays: depth 0 only
 
-	// Primary batch: small enough that the ray tree cannot outgrow a queue even if every hit
-	// spawns the most children its scene's materials allow.
-	uint64_t batch = sc->queue_capacity;
-	if (sc->branching) batch = std::max<uint64_t>(sc->queue_capacity >> std::min(max_depth, 31u), 1u << 16);
-	batch = std::min<uint64_t>(batch, 1ull << 30);
-	batch &= ~63ull;
-
 	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 1024, stream));
 	uint64_t launches = 0;
-	for (uint64_t first = 0; first < total; first += batch) {
-		unsigned cnt = (unsigned) std::min<uint64_t>(batch, total - first);
-		HIP_TRY(hipMemsetAsync(sc->d_counts, 0, 1024, stream));
-		A.first = first;
-		A.batch = cnt;
-		A.depth = 0;
-		A.last_depth = (max_depth == 0);
-		A.in = sc->q[1];
-		A.out = sc->q[0];
-		A.in_count = nullptr;
-		A.out_count = sc->d_counts + 1;
-		unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
-		hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
-		++launches;
-		for (unsigned d = 1; d <= max_depth; ++d) {
-			A.depth = d;
-			A.last_depth = (d == max_depth);
-			A.in = sc->q[(d - 1) & 1];
-			A.out = sc->q[d & 1];
-			A.in_count = sc->d_counts + d;
-			A.out_count = sc->d_counts + d + 1;
-			hipLaunchKernelGGL(k_bounce<false>, dim3(sc->grid), dim3(kBlock), 0, stream, A);
-			++launches;
+	const bool prof = sc->profiling && stats;
+	sc->event_depth.clear();
+	auto tick = [&](unsigned depth, bool begin) -> hipError_t {
+		if (!prof) return hipSuccess;
+		size_t k = sc->event_depth.size() * 2 + (begin ? 0 : 1);
+		while (sc->events.size() <= k) {
+			hipEvent_t e;
+			hipError_t err = hipEventCreate(&e);
+			if (err != hipSuccess) return err;
+			sc->events.push_back(e);
 		}
+		hipError_t err = hipEventRecord(sc->events[k], stream);
+		if (!begin) sc->event_depth.push_back(depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1);
+		return err;
+	};
+	auto queue_at = [&](uint64_t first_slot, uint64_t cap) {
+		RayQueue q;
+		q.a = sc->qmem + first_slot * 3;
+		q.b = q.a + cap;
+		q.c = q.b + cap;
+		return q;
+	};
+	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountStride; };
+
+	// Two ways to drive the ray tree through the queues.
+	//  (1) no host synchronisation: two ping-pong queues, and a primary batch so small that
+	//      even if every hit spawned the most children the scene's materials allow, depth
+	//      max_depth could not outgrow a queue.  Every launch reads its ray count on the device.
+	//  (2) when that batch would be too small to fill the GPU (deep trees of two-child
+	//      materials): one queue per depth, the rays of a depth are taken in chunks whose
+	//      children are certain to fit the next queue, and the host reads one counter per
+	//      launch to learn how many there are (depth-first over the chunks).
+	const uint64_t cap2 = (sc->qrays / 2) & ~63ull;
+	const uint64_t growth_safe = sc->branching ? (max_depth < 40 ? cap2 >> max_depth : 0) : cap2;
+	const bool sync_free = max_depth == 0 || growth_safe >= (1u << 18);
+	if (sync_free) {
+		uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(growth_safe, 64), 1ull << 30) & ~63ull;
+		RayQueue q[2] = {queue_at(0, cap2), queue_at(cap2, cap2)};
+		A.out_capacity = A.in_capacity = (unsigned) cap2;
+		for (uint64_t first = 0; first < total; first += batch) {
+			unsigned cnt = (unsigned) std::min<uint64_t>(batch, total - first);
+			if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountStride * sizeof(unsigned), stream));
+			A.first = first;
+			A.batch = cnt;
+			A.depth = 0;
+			A.last_depth = (max_depth == 0);
+			A.in = q[1];
+			A.out = q[0];
+			A.in_count = nullptr;
+			A.in_offset = 0;
+			A.out_count = count_of(1);
+			unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
+			HIP_TRY(tick(0, true));
+			hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
+			HIP_TRY(tick(0, false));
+			++launches;
+			for (unsigned d = 1; d <= max_depth; ++d) {
+				A.depth = d;
+				A.last_depth = (d == max_depth);
+				A.in = q[(d - 1) & 1];
+				A.out = q[d & 1];
+				A.in_count = count_of(d);
+				A.out_count = count_of(d + 1);
+				HIP_TRY(tick(d, true));
+				hipLaunchKernelGGL(k_bounce<false>, dim3(sc->grid), dim3(kBlock), 0, stream, A);
+				HIP_TRY(tick(d, false));
+				++launches;
+			}
+		}
+	} else {
+		const uint64_t capd = (sc->qrays / max_depth) & ~63ull;  // queue d (1..max_depth) holds the rays traced at depth d
+		const unsigned chunk = (unsigned) std::min<uint64_t>((sc->branching ? capd / 2 : capd) & ~63ull, 1u << 30);
+		if (chunk < 64) return fail(PTX_ERR_NOMEM, "queue_bytes too small for max_ray_bounces: raise queue_bytes in ptx_scene_create");
+		A.out_capacity = A.in_capacity = (unsigned) capd;
+		A.in_count = nullptr;
+		PtxStatus rst = PTX_OK;
+		// rays [0, n) of queue d are traced in chunks; each chunk's children go to queue d+1 and are
+		// finished (recursively) before the next chunk overwrites that queue
+		auto run = [&](auto&& self, unsigned d, unsigned n) -> PtxStatus {
+			for (unsigned off = 0; off < n; off += chunk) {
+				unsigned cnt = std::min(chunk, n - off);
+				const bool last = (d == max_depth);
+				if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountStride * sizeof(unsigned), stream));
+				A.depth = d;
+				A.last_depth = last;
+				A.batch = cnt;
+				A.in_offset = off;
+				A.out_count = count_of(d + 1);
+				if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
+				A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
+				unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
+				HIP_TRY(tick(d, true));
+				if (d == 0) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
+				else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+				HIP_TRY(tick(d, false));
+				++launches;
+				if (last) continue;
+				unsigned m = 0;
+				HIP_TRY(hipMemcpyAsync(&m, count_of(d + 1), sizeof m, hipMemcpyDeviceToHost, stream));
+				HIP_TRY(hipStreamSynchronize(stream));
+				if (m > capd) m = (unsigned) capd;  // cannot happen by construction; the overflow flag reports it
+				if (m) {
+					PtxStatus st2 = self(self, d + 1, m);
+					if (st2 != PTX_OK) return st2;
+				}
+			}
+			return PTX_OK;
+		};
+		for (uint64_t first = 0; first < total && rst == PTX_OK; first += chunk) {
+			A.first = first;
+			rst = run(run, 0, (unsigned) std::min<uint64_t>(chunk, total - first));
+		}
+		if (rst != PTX_OK) return rst;
 	}
 	HIP_TRY(hipGetLastError());
 	if (check_overflow || stats) {
@@ -1025,7 +1134,18 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 			stats->shadow_rays = c.shadow_rays;
 			stats->shaded_hits = c.shaded_hits;
 			stats->launches = launches;
-			for (int k = 0; k < kMaxDepthSlots; ++k) stats->per_depth_rays[k] = c.per_depth[k];
+			for (int k = 0; k < kMaxDepthSlots; ++k) {
+				stats->per_depth_rays[k] = c.per_depth[k];
+				stats->per_depth_shadow[k] = c.per_depth_shadow[k];
+				stats->per_depth_hits[k] = c.per_depth_hits[k];
+			}
+			if (prof)
+				for (size_t k = 0; k < sc->event_depth.size(); ++k) {
+					float ms = 0;
+					HIP_TRY(hipEventElapsedTime(&ms, sc->events[2 * k], sc->events[2 * k + 1]));
+					stats->per_depth_ms[sc->event_depth[k]] += ms;
+					stats->per_depth_launches[sc->event_depth[k]] += 1;
+				}
 		}
 		if (c.overflow)
 			return fail(PTX_ERR_OVERFLOW, "a ray queue overflowed (" + std::to_string(c.overflow) +

@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/ptx.h declares; without a GPU
+the device entry points fail loudly instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "ptx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_library_agree(pt):
+    L = pt.ptx_lib()
+    names = declared_symbols()
+    assert sorted(pt.PTX_SYMBOLS) == names
+    for n in names:
+        assert hasattr(L, n), f"libptx.so does not export {n}"
+    assert b"gfx950" in L.ptx_version()
+
+
+def test_library_holds_gfx950_code_only(pt):
+    so = os.path.join(REPO, "path-tracer_amd", "libptx.so")
+    blob = open(so, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_90"):
+        assert other not in blob
+
+
+def test_struct_sizes_match_the_header(pt):
+    # sizes implied by the field lists of include/ptx.h
+    assert ctypes.sizeof(pt.PtxMaterial) == 13 * 4
+    assert ctypes.sizeof(pt.PtxLight) == 6 * 4
+    assert ctypes.sizeof(pt.PtxCamera) == 10 * 4
+    assert ctypes.sizeof(pt.PtxFrame) == (16 + 16 + 6 + 2) * 4
+    assert ctypes.sizeof(pt.PtxPrim) == (4 + 9 + 3 + 32) * 4
+    assert ctypes.sizeof(pt.PtxRenderParams) == 6 * 4
+    assert ctypes.sizeof(pt.PtxStats) == 5 * 8 + 5 * 16 * 8
+
+
+def test_no_device_means_loud_failure(pt, scenes):
+    if pt.device_count() > 0:
+        pytest.skip("a GPU is present: the failure path is for boxes without one")
+    with pytest.raises(pt.PtxError) as e:
+        pt.DeviceScene(scenes.host_scene("cornell"))
+    assert e.value.status == 3 and "no CPU path" in str(e.value)
+
+
+def test_bad_arguments_are_rejected_without_a_device(pt):
+    L = pt.ptx_lib()
+    out = ctypes.c_void_p()
+    assert L.ptx_scene_create(None, 0, 0, ctypes.byref(out)) == 1
+    assert b"NULL" in L.ptx_last_error()
+    assert L.ptx_write_ppm(None, None, 1, 1) == 1
+    assert L.ptx_scene_set_profiling(None, 1) == 1

@@ -1,0 +1,215 @@
+"""Parity of the gfx950 path with the reference, through the C ABI of include/ptx.h.
+
+Bars (stated here, asserted below):
+  * hit identity  - the prim a ray hits names the same Shape as the reference's
+                    HitPoint::hit_object, for every ray (exact);
+  * hit distance  - the requirement is |t - t_ref| <= 1e-5 * |t_ref|; what is asserted is
+                    stricter: t, position, normal and ray_direction are BIT-identical;
+  * images        - same sample grid as the reference, so per-pixel RMSE of the tone-mapped
+                    float image <= 1e-6, max abs error <= 1e-5, and the 8-bit PPM values
+                    differ in at most 0.1 % of the bytes, never by more than 1
+                    (only the order of the fp32 sums differs from the CPU loop).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, beq, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RMSE_MAX = 1e-6
+ABS_MAX = 1e-5
+
+
+def image_errors(color, ref_color, rgb, ref_rgb):
+    diff = color.astype(np.float64) - ref_color.astype(np.float64)
+    both_nan = np.isnan(color) & np.isnan(ref_color)
+    diff[both_nan] = 0
+    rmse = float(np.sqrt(np.mean(diff ** 2)))
+    bd = np.abs(rgb.astype(int) - ref_rgb.astype(int))
+    return rmse, float(np.max(np.abs(diff))), float((bd > 0).mean()), int(bd.max())
+
+
+def assert_image_close(color, ref_color, rgb, ref_rgb):
+    rmse, mx, frac, worst = image_errors(color, ref_color, rgb, ref_rgb)
+    assert rmse <= RMSE_MAX, rmse
+    assert mx <= ABS_MAX, mx
+    assert frac <= 1e-3 and worst <= 1, (frac, worst)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_hits_equal_reference_golden(pt, scenes, name):
+    g = load_golden(name)
+    ds = scenes.device_scene(name)
+    names = scenes.host_scene(name).prim_names()
+    table = [str(x) for x in g["names"]]
+    hw, hh = int(g["hit_w"]), int(g["hit_h"])
+    prim, t = ds.primary_hits(hw, hh, 1, 0)
+    got = [names[i] if i >= 0 else "null" for i in prim]
+    assert got == [table[i] for i in g["primary_name"]]
+    hit = prim >= 0
+    assert beq(t[hit], g["primary_t"][hit])
+    a = ds.intersect(g["rays_o"], g["rays_d"])
+    got = [names[i] if i >= 0 else "null" for i in a["prim"]]
+    assert got == [table[i] for i in g["rays_name"]]
+    m = a["hit"]
+    assert m.sum() > 100
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], g["rays_" + k][m]), k
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_hits_equal_oracle_many_rays(pt, port, scenes, name):
+    """More rays than the fixtures hold: 480x320 primary rays of two aa samples + 60 000 incoherent rays."""
+    from oracle_lib import random_rays
+    ds, s = scenes.device_scene(name), scenes.oracle_scene(name)
+    o, d = port.primary_rays(s, 480, 320, 1)
+    o2, d2 = random_rays(60000, 20241111)
+    o = np.concatenate([o, o2])
+    d = np.concatenate([d, d2])
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    rel = np.abs(a["t"][m] - b["t"][m]) / np.abs(b["t"][m])
+    assert rel.max() <= 1e-5
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    # the aa grid: sample 5 of a 3x3 grid
+    prim, t = ds.primary_hits(200, 120, 3, 5)
+    o3, d3 = port.primary_rays(s, 200, 120, 3)
+    b = port.intersect(s, o3[5::9], d3[5::9])
+    assert np.array_equal(prim, b["rank"]) and beq(t[b["hit"]], b["t"][b["hit"]])
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_image_equals_reference_golden(pt, scenes, name):
+    g = load_golden(name)
+    w, h, aa, nb = (int(v) for v in g["params"])
+    r = scenes.device_scene(name).render_image(w, h, aa, nb)
+    assert_image_close(r["color"], g["color"], r["rgb"], g["rgb"])
+    assert r["stats"]["samples"] == w * h * aa * aa
+
+
+def test_config1_image(pt, scenes):
+    """BASELINE config 1 (cornell.sdf 480x320, 16 spp, 5 bounces) against the reference's PPM."""
+    g = load_golden("config1_cornell_480x320_aa4")
+    w, h, aa, nb = (int(v) for v in g["params"])
+    r = scenes.device_scene("cornell").render_image(w, h, aa, nb)
+    bd = np.abs(r["rgb"].astype(int) - g["rgb"].astype(int))
+    assert (bd > 0).mean() <= 1e-3 and bd.max() <= 1
+
+
+@pytest.mark.parametrize("name,w,h,aa,nb", [("cornell", 320, 200, 3, 5), ("cornell", 64, 48, 2, 0), ("cornell", 64, 48, 2, 1),
+                                            ("example_fixed", 320, 180, 2, 3), ("cornell_buster", 200, 120, 2, 5),
+                                            ("superhot_colored", 256, 144, 2, 4), ("example", 1, 1, 1, 5), ("example", 7, 3, 5, 2)])
+def test_image_equals_oracle(pt, port, scenes, name, w, h, aa, nb):
+    r = scenes.device_scene(name).render_image(w, h, aa, nb)
+    ref = port.render(scenes.oracle_scene(name), w, h, aa, nb)
+    assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+
+
+def test_drop_in_renderer_writes_the_reference_ppm(pt, scenes, tmp_path):
+    """Renderer{w,h,file,aa,bounces}.render(scene) through the host-side C++ class."""
+    g = load_golden("cornell")
+    w, h, aa, nb = (int(v) for v in g["params"])
+    out = tmp_path / "img.ppm"
+    color, sec = scenes.host_scene("cornell").render_file(w, h, aa, nb, str(out))
+    text = out.read_bytes()
+    vals = np.array(text.split()[4:], dtype=np.int32).astype(np.uint8).reshape(h, w, 3)
+    assert text.startswith(b"P3 %d %d 255 \n" % (w, h))
+    assert_image_close(color, g["color"], vals, g["rgb"])
+    if np.array_equal(vals, g["rgb"]):
+        assert hashlib.md5(text).hexdigest() == str(g["ppm_md5"])
+
+
+def test_sample_ranges_add_up(pt, scenes):
+    """Multi-GPU split: accumulating [0,k) and [k,n) gives the full image (fp32 sums reordered)."""
+    import torch
+    ds = scenes.device_scene("example_fixed")
+    w, h, aa, nb = 160, 90, 4, 5
+    full = ds.render_image(w, h, aa, nb)
+    acc = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for b, e in ((0, 5), (5, 6), (6, 16)):
+        ds.render_accumulate(pt.render_params(w, h, aa, nb, b, e), acc.data_ptr(), stream, check_overflow=True)
+    color = torch.empty(h * w * 3, dtype=torch.float32, device="cuda:0")
+    rgb = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    ds.resolve(acc.data_ptr(), w, h, aa * aa, color.data_ptr(), rgb.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert_image_close(color.cpu().numpy().reshape(h, w, 3), full["color"], rgb.cpu().numpy().reshape(h, w, 3), full["rgb"])
+    # an empty range adds nothing
+    before = acc.clone()
+    ds.render_accumulate(pt.render_params(w, h, aa, nb, 7, 7), acc.data_ptr(), stream, check_overflow=True)
+    torch.cuda.synchronize()
+    assert torch.equal(before, acc)
+
+
+def test_work_counters(pt, port, scenes):
+    """The kernels count their rays; primary rays equal samples and hits never exceed the
+    oracle's count (rays whose weight is exactly zero are not traced on the GPU)."""
+    w, h, aa, nb = 120, 80, 2, 5
+    r = scenes.device_scene("cornell").render_image(w, h, aa, nb)
+    ref = port.render(scenes.oracle_scene("cornell"), w, h, aa, nb, counters=True)
+    st = r["stats"]
+    assert st["per_depth_rays"][0] == w * h * aa * aa
+    assert st["trace_rays"] == sum(st["per_depth_rays"])
+    assert st["trace_rays"] <= int(ref["counters"][0]) and st["shadow_rays"] <= int(ref["counters"][1])
+    assert st["shaded_hits"] <= st["trace_rays"]
+
+
+def test_edge_cases(pt, tmp_path):
+    # no shapes at all: every ray misses, image is black
+    sdf = tmp_path / "empty.sdf"
+    sdf.write_text("define camera eye 60 0 0 10 0 0 0\n")
+    ds = pt.DeviceScene(pt.HostScene(str(sdf)), 0, 1 << 26)
+    r = ds.render_image(16, 8, 2, 5)
+    assert not r["color"].any() and not r["rgb"].any()
+    a = ds.intersect([[0, 0, 0]], [[0, 0, -1]])
+    assert a["prim"][0] == -1
+    # a lone mesh, rays along coordinate axes (zero direction components) and from inside bounds
+    sdf = tmp_path / "mesh.sdf"
+    sdf.write_text("define shape obj sword\ndefine light l 0 20 20 1 1 1 1\ndefine camera eye 60 0 1 8 0 0 0\n")
+    hs = pt.HostScene(str(sdf), pt.SDF_DIR + "/")
+    ds = pt.DeviceScene(hs, 0, 1 << 26)
+    import sys
+    from oracle_lib import Port
+    port = Port()
+    s = port.load(str(sdf), pt.SDF_DIR + "/")
+    o = np.array([[0, 1, 8], [0, 0.5, 0], [0.1, 5, 0.05], [3, 0.3, 0], [0, 0, 0]], np.float32)
+    d = np.array([[0, 0, -1], [0, 1, 0], [0, -1, 0], [-1, 0, 0], [0, 0, 0]], np.float32)
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    assert beq(a["t"][b["hit"]], b["t"][b["hit"]])
+    # bad arguments
+    with pytest.raises(pt.PtxError):
+        ds.render_image(0, 8, 1, 1)
+    with pytest.raises(pt.PtxError):
+        ds.render_image(8, 8, 2, 1, 3, 9)
+
+
+def test_deep_two_child_trees_in_small_queues(pt, port, tmp_path):
+    """Every hit on this scene spawns a reflection AND a refraction ray.  With the smallest
+    queue the library has to walk the ray tree depth-first in chunks (one queue per depth, the
+    host reading one counter per launch); with a large queue it runs without any host
+    synchronisation.  Both must give the reference's image, and none may drop a ray."""
+    sdf = tmp_path / "glass.sdf"
+    sdf.write_text("define material glass 0 0 1 0 0 1 1 1 1 10 0.5 0.5 1.4\n"
+                   "define shape sphere a 0 0 -5 4 glass\ndefine shape sphere b 0 0 -5 3 glass\n"
+                   "define shape sphere c 0 0 -5 2 glass\ndefine shape box w -30 -30 -40 30 30 -30 glass\n"
+                   "define light l 0 20 20 1 1 1 1\ndefine camera eye 40 0 0 10 0 0 0\n")
+    hs = pt.HostScene(str(sdf))
+    s = port.load(str(sdf))
+    small = pt.DeviceScene(hs, 0, 1)        # clamps to the minimum queue memory
+    big = pt.DeviceScene(hs, 0, 2 << 30)
+    for w, h, aa, nb in ((96, 96, 2, 6), (48, 48, 1, 11)):
+        ref = port.render(s, w, h, aa, nb, counters=True)
+        for ds in (small, big):
+            r = ds.render_image(w, h, aa, nb)
+            assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+            assert r["stats"]["trace_rays"] > 3 * w * h * aa * aa
+    # the two strategies do the same work
+    a, b = small.render_image(96, 96, 2, 6)["stats"], big.render_image(96, 96, 2, 6)["stats"]
+    assert a["trace_rays"] == b["trace_rays"] and a["shadow_rays"] == b["shadow_rays"]
+    assert a["launches"] > b["launches"]

@@ -1,0 +1,106 @@
+"""The CPU oracle (oracle/cpu_ref.cpp) against the golden vectors the real reference produced
+(tests/golden/, written by oracle/gen_golden.py from the reference's own sources).
+Everything here is bit-exact: the oracle restates the reference's fp32 operation order."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, beq, load_golden
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_image_equals_reference(port, scenes, name):
+    g = load_golden(name)
+    w, h, aa, nb = (int(v) for v in g["params"])
+    r = port.render(scenes.oracle_scene(name), w, h, aa, nb)
+    assert beq(r["color"], g["color"]), "Renderer::color_buffer() differs from the reference"
+    assert np.array_equal(r["rgb"], g["rgb"])
+    assert hashlib.md5(port.ppm_text(r["rgb"])).hexdigest() == str(g["ppm_md5"])
+
+
+def test_oracle_config1_md5(port, scenes):
+    """BASELINE config 1: cornell.sdf 480x320, 16 spp, 5 bounces; md5 recorded from the reference."""
+    g = load_golden("config1_cornell_480x320_aa4")
+    w, h, aa, nb = (int(v) for v in g["params"])
+    r = port.render(scenes.oracle_scene("cornell"), w, h, aa, nb)
+    assert np.array_equal(r["rgb"], g["rgb"])
+    assert hashlib.md5(port.ppm_text(r["rgb"])).hexdigest() == str(g["ppm_md5"]) == "08e2d136a052bafcf2550b038edb801b"
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_hits_equal_reference(port, scenes, name):
+    g = load_golden(name)
+    s = scenes.oracle_scene(name)
+    leaf = port.leaf_names(s)
+    table = [str(x) for x in g["names"]]
+    hw, hh = int(g["hit_w"]), int(g["hit_h"])
+    o, d = port.primary_rays(s, hw, hh, 1)
+    a = port.intersect(s, o, d)
+    names = [leaf[r] if r >= 0 else "null" for r in a["rank"]]
+    assert names == [table[i] for i in g["primary_name"]]
+    assert beq(a["t"][a["hit"]], g["primary_t"][a["hit"]])
+    a = port.intersect(s, g["rays_o"], g["rays_d"])
+    names = [leaf[r] if r >= 0 else "null" for r in a["rank"]]
+    assert names == [table[i] for i in g["rays_name"]]
+    m = a["hit"]
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], g["rays_" + k][m]), k
+
+
+def test_oracle_primitives_equal_reference(port):
+    g = load_golden("primitives")
+    o, d = g["rays_o"], g["rays_d"]
+    for i in range(int(g["n_prims"])):
+        a = port.prim_intersect(int(g[f"kind{i}"]), g[f"p{i}"], g[f"xf{i}"], o, d)
+        assert np.array_equal(a["hit"], g[f"hit{i}"])
+        m = a["hit"]
+        assert m.sum() > 20
+        for k in ("t", "pos", "normal", "raydir"):
+            assert beq(a[k][m], g[f"{k}{i}"][m]), (i, k)
+
+
+def test_reference_unit_test_cases(port, tmp_path):
+    """The cases of the reference's source/tests.cpp (same shapes, same rays), with the values the
+    code gives today: every intersector subtracts EPSILON = 0.001 from t, so the file's own
+    expectations 8.0 (tests.cpp:83) and 10 (tests.cpp:118) read 7.999 and 9.999."""
+    eps = np.float32(0.001)
+    ray = ([[0, 0, 0]], [[0, 0, 1]])
+    # tests.cpp:76-96 intersect_ray_sphere2
+    s0 = port.prim_intersect(0, [0, 0, 10, 2], [], *ray)
+    assert s0["hit"][0] and s0["t"][0] == np.float32(8.0) - eps and np.allclose(s0["pos"][0], [0, 0, 7.999], atol=1e-6)
+    s1 = port.prim_intersect(0, [4, 0, 10, 2], [], *ray)
+    assert not s1["hit"][0]
+    s2 = port.prim_intersect(0, [2, 0, 10, 2], [], *ray)
+    assert s2["hit"][0] and abs(float(s2["t"][0]) - 9.999) < 1e-3
+    g = load_golden("primitives")  # the reference's answers for the same sphere KAT layout
+    a = port.prim_intersect(0, [0, 0, 0, 2], [], g["kat_o"], g["kat_d"])
+    assert np.array_equal(a["hit"], g["kat_hit"]) and beq(a["t"], g["kat_t"])
+    # tests.cpp:112-142 box_ray_intersection
+    box = [-10, -10, -10, 10, 10, 10]
+    b = port.prim_intersect(1, box, [], [[5, 5, -20], [20, 20, 0], [-20, -20, -20], [10, 30, 10], [0, 0, 20]],
+                            [[0, 0, 1], [0, 0, 1], [1, 20, 1], [-1, -1, -1], [0, 0, 1]])
+    assert list(b["hit"]) == [True, False, False, True, False]
+    assert b["t"][0] == np.float32(10.0) - eps and np.allclose(b["pos"][0], [5, 5, -10], atol=1.1e-3)
+    assert b["t"][3] == np.float32(20.0) - eps and np.allclose(b["pos"][3], [-10, 10, -10], atol=1.1e-3)
+    # tests.cpp:144-158 triangle_ray_intersection
+    t = port.prim_intersect(2, [-1, 0, -1, 0, 0, 1, 1, 0, -1], [], [[0, 10, 0], [1, 10, 1], [10, 0, 0]], [[0, -1, 0], [0, -1, 0], [-1, 0, 0]])
+    assert list(t["hit"]) == [True, False, False]
+    # tests.cpp:160-176 composite_ray_intersection: the nearer child wins
+    sdf = tmp_path / "comp.sdf"
+    sdf.write_text("define material m 1 1 1 1 1 1 0 0 0 0 0 1 1\n"
+                   "define shape sphere back 0 0 -1 1 m\n"
+                   "define shape box front -1 -1 0 1 1 2 m\n")
+    sc = port.load(str(sdf))
+    c = port.intersect(sc, [[0, 10, 1], [0, 10, -1]], [[0, -1, 0], [0, -1, 0]])
+    names = port.leaf_names(sc)
+    assert [names[r] for r in c["rank"]] == ["front", "back"]
+    # tests.cpp:235-250 transform box: Box{{0,0,0},{1,1,3}}.rotate(PI/2, 0, 0)
+    mn, mx = port.box_bounds([0, 0, 0, 1, 1, 3], [[2, np.float32(3.14159265) / 2, 0, 0]])
+    assert np.allclose(mn, [0, 0, -1], atol=1e-6) and np.allclose(mx, [3, 1, 0], atol=1e-6)
+    # tests.cpp:252-259 scale sphere: prints position (0,0,2.001), normal (0,0,1)
+    s = port.prim_intersect(0, [0, 0, 0, 1], [[3, 2, 2, 2]], [[0, 0, 10]], [[0, 0, -1]])
+    assert s["hit"][0] and np.allclose(s["pos"][0], [0, 0, 2.001], atol=1e-5) and np.allclose(s["normal"][0], [0, 0, 1], atol=1e-6)
+    # tests.cpp:33-45 / box.cpp:14-16: min > max throws
+    with pytest.raises(ValueError):
+        port.prim_intersect(1, [1, 0, 0, 0, 1, 1], [], [[0, 0, 0]], [[0, 0, 1]])
