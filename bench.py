@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Throughput of the render path on MI355X: path-samples per second.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): sdf/example.sdf at 1920x1080, aa_steps = 32 (1024 samples
+per pixel on the reference's regular sub-pixel grid), max_ray_bounces = 5.  One step = one
+complete Renderer::render of that image: every rank renders ALL pixels for its slice of the
+1024 per-pixel samples into its own fp32 accumulation buffer, the buffers are summed onto
+rank 0 with one RCCL reduce, rank 0 resolves (average, tone map, 8-bit rows).  The scene is
+resident in HBM before the timed region starts; the image stays on the device.
+
+The JSON line also carries
+  roofline      the dominant kernel (the depth-0 bounce kernel): algorithmic bytes per launch
+                (176 B per ray segment + 24 B per shaded hit, rays and hits counted by the
+                kernel itself) / its average launch duration from HIP events recorded on
+                the launch stream during the timed steps, against 8 TB/s;
+  cpu_baseline  the CPU oracle (oracle/cpu_ref.cpp, the bit-exact restatement of the
+                reference renderer) timed on this box's host cores on a bounded sample of
+                the same workload (same scene and resolution, fewer samples per pixel).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
+VALU_PEAK_TFLOPS = 157.3    # vector fp32, FMA counted as 2
+BYTES_PER_RAY = 176         # ray record written + read by intersect + read by shade (3 x 48) + hit record written + read (2 x 16)
+BYTES_PER_HIT = 24          # float3 accumulator read-modify-write
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="example.sdf")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--aa", type=int, default=32)
+    ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--queue-gib", type=float, default=16.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration; 0 skips it")
+    ap.add_argument("--cpu-kind", choices=["port", "reference"], default="port")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel launches with HIP events")
+    ap.add_argument("--save-ppm", default=None)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, scene_path):
+    """Oracle timed on the host cores: same scene and resolution, aa chosen for ~cpu_seconds."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_lib
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    if args.cpu_kind == "reference" and oracle_lib.Reference.available():
+        lib, kind = oracle_lib.Reference(), "reference"
+        threads = os.cpu_count() or 1  # the reference spawns hardware_concurrency() threads (framework/renderer.cpp:39)
+    else:
+        lib, kind = oracle_lib.Port(), "port"
+    s = lib.load(scene_path)
+    w, h, nb = args.width, args.height, args.bounces
+    probe = lib.render(s, w, h, 1, nb, threads=threads)
+    rate = w * h / max(probe["seconds"], 1e-6)
+    aa = max(1, min(args.aa, int((args.cpu_seconds * rate / (w * h)) ** 0.5)))
+    r = lib.render(s, w, h, aa, nb, threads=threads)
+    samples = w * h * aa * aa
+    return {"value": samples / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": f"{args.scene} {w}x{h}, aa_steps={aa} ({aa * aa} of {args.aa * args.aa} spp), {nb} bounces, {r['seconds']:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    pt = importlib.import_module("path-tracer_amd")
+    ptdist = importlib.import_module("path-tracer_amd.dist")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world != args.gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    scene_path = os.path.join(pt.SDF_DIR, args.scene)
+    host = pt.HostScene(scene_path)
+    ds = pt.DeviceScene(host, local_rank, int(args.queue_gib * (1 << 30)))
+    profile = not args.no_profile
+    ds.set_profiling(profile)
+
+    w, h, aa, nb = args.width, args.height, args.aa, args.bounces
+    spp = aa * aa
+    s0, s1 = ptdist.sample_range(rank, world, spp)
+    rp = pt.render_params(w, h, aa, nb, s0, s1)
+    accum = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+    color = torch.empty(w * h * 3, dtype=torch.float32, device=dev) if rank == 0 else None
+    rgb = torch.empty(w * h * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        accum.zero_()
+        st = ds.render_accumulate(rp, accum.data_ptr(), stream, check_overflow=True, want_stats=True)
+        ptdist.reduce_accum(accum, 0)
+        if rank == 0:
+            ds.resolve(accum.data_ptr(), w, h, spp, color.data_ptr(), rgb.data_ptr(), stream)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = None
+    for _ in range(args.steps):
+        stats = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples_per_step = w * h * spp
+        value = samples_per_step * args.steps / elapsed / 1e6
+        out = {
+            "metric": "path samples/sec", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (scene file shipped with the reference; regular sample grid, no RNG)",
+            "config": {"workload": f"{args.scene} {w}x{h}, aa_steps={aa} ({spp} spp), max_ray_bounces={nb}",
+                       "samples_per_step": samples_per_step, "parallelism": f"sample-range x{world}, one RCCL sum-reduce per image"},
+        }
+        # ---- work done by this rank in the last step (the kernels count it themselves)
+        R = (stats["trace_rays"] + stats["shadow_rays"])
+        H = stats["shaded_hits"]
+        my_samples = stats["samples"]
+        out["work"] = {"rays_per_sample": R / my_samples, "shaded_hits_per_sample": H / my_samples,
+                       "trace_rays_per_sample": stats["trace_rays"] / my_samples, "shadow_rays_per_sample": stats["shadow_rays"] / my_samples,
+                       "algorithmic_bytes_per_sample": (BYTES_PER_RAY * R + BYTES_PER_HIT * H) / my_samples,
+                       "Mrays/s": R * world * args.steps / elapsed / 1e6 if world == 1 else None,
+                       "kernel_launches_per_step": stats["launches"]}
+        if profile and stats["per_depth_launches"][0]:
+            n0 = stats["per_depth_launches"][0]
+            ms0 = stats["per_depth_ms"][0]
+            bytes0 = BYTES_PER_RAY * (stats["per_depth_rays"][0] + stats["per_depth_shadow"][0]) + BYTES_PER_HIT * stats["per_depth_hits"][0]
+            achieved = bytes0 / (ms0 * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_bounce<true> (depth 0: ray generation + closest hit + shading + shadow + emit + accumulate)",
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "launches": n0, "avg_launch_ms": ms0 / n0, "algorithmic_bytes_per_launch": bytes0 / n0}
+            tot_ms = sum(stats["per_depth_ms"])
+            tot_bytes = BYTES_PER_RAY * R + BYTES_PER_HIT * H
+            out["kernel_time"] = {"per_depth_ms": [round(x, 3) for x in stats["per_depth_ms"][: nb + 1]],
+                                  "per_depth_rays": stats["per_depth_rays"][: nb + 1],
+                                  "all_bounce_launches_ms": tot_ms, "all_bounce_launches_algorithmic_GBs": tot_bytes / (tot_ms * 1e-3) / 1e9}
+        else:
+            out["roofline"] = None
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, scene_path)
+        else:
+            out["cpu_baseline"] = None
+        if args.save_ppm:
+            pt.write_ppm(args.save_ppm, rgb.cpu().numpy().reshape(h, w, 3))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

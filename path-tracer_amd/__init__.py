@@ -95,7 +95,7 @@ def _load(name):
 
 
 def ptx_lib():
-    L = _load("libptx.so")
+    L = _load(os.environ.get("PTX_LIB", "libptx.so"))
     if getattr(L, "_typed", False):
         return L
     vp = C.c_void_p

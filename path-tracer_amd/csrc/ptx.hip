@@ -37,43 +37,90 @@ using namespace ptxd;
 namespace {
 
 constexpr int kBlock = 256;  // 4 wave64 per workgroup
+#ifndef PTX_MIN_WAVES
+#define PTX_MIN_WAVES 2  // waves per SIMD the bounce kernel's register budget is sized for
+#endif
 constexpr int kStack = 32;   // per-lane BVH stack slots in LDS (>= ptx::kBvhMaxDepth)
 static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
 constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
 constexpr unsigned kMaxBounces = 63;
-constexpr unsigned kCountStride = 64;           // one queue counter per 256-B line
-constexpr size_t kCountBytes = (kMaxBounces + 2) * kCountStride * sizeof(unsigned);
+// A ray queue is cut into kNQ sub-queues, each with its own tail counter on its own 128-B
+// line.  A wave appends the children of its k-th 64-ray step to sub-queue (k mod kNQ) with
+// one returning atomic.  With ONE tail word every wave of the chip queues up behind the same
+// address (adds to one word retire one at a time, roughly 10 ns each, which made the append
+// the most expensive step of a bounce); spread over 64 words they proceed in parallel, and
+// because consecutive steps go to consecutive sub-queues every sub-queue fills evenly.
+constexpr unsigned kNQ = 64;
+constexpr unsigned kCountPad = 32;  // words between two tail counters
+constexpr unsigned kCountsPerDepth = kNQ * kCountPad;
+constexpr size_t kCountBytes = (size_t) (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);
 
 // ---------------------------------------------------------------------------
 // device scene
 // ---------------------------------------------------------------------------
-struct DevRootPrim {  // a leaf of frame 0 (tested by every ray, wave-uniform access)
-	float winv[16];
-	float w[16];
-	float p[9];  // sphere: c, r | box: lo, hi | triangle: v0, e1, e2
-	float n[3];
-	int32_t kind, id, levels_in, material;
+// pointer to read-only scene data as the DEVICE pass sees it (constant address space, which
+// lets uniform reads become scalar loads); the host pass only stores the address
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PTX_KPTR(T) const __attribute__((address_space(4))) T*
+#else
+#define PTX_KPTR(T) const T*
+#endif
+
+constexpr int kPlain = 1 << 8;  // the shape's own transform is a pure translation: local = x + t, bit for bit
+
+struct DevRootPrim {  // a leaf of frame 0, tested by every ray: 64 B, fetched with one wave-uniform scalar load
+	float tinv[3];       // translation column of world_transform_inv_
+	int32_t kind_flags;  // PtxPrimKind | kPlain
+	float p[9];          // sphere: c, r | box: lo, hi | triangle: v0, e1, e2
+	int32_t id;
+	int32_t xform;       // index into DevScene::xforms when the transform is not a pure translation
+	int32_t pad;
 };
-struct DevFrame {  // a transformed mesh Composite
+struct DevXform {  // full matrices of a leaf whose transform rotates or scales
 	float winv[16];
 	float w[16];
-	float bmin[3], bmax[3];
+};
+struct DevRootShade {  // what shading needs of a frame-0 leaf, per root slot
+	float tw[3];  // translation column of world_transform_
+	int32_t material;
+	float n[3];   // triangle: n_
+	int32_t levels_in;
+};
+struct DevFrame {  // a mesh Composite with its own transform and bounds: 64-B head + matrices
+	float bmin[3];
 	int32_t bvh_root;   // child reference, node indices relative to node_base
+	float bmax[3];
 	int32_t node_base;  // first float4 of this frame's nodes
+	float tinv[3];      // translation column of world_transform_inv_
 	int32_t tri_base;   // first float4 of this frame's triangle records
 	int32_t levels_up;
 	int32_t has_prims;
-	int32_t pad[3];
+	int32_t plain;      // transform is a pure translation
+	int32_t pad;
+};
+struct Mat16 {
+	float m[16];
 };
 struct DevScene {
 	const DevRootPrim* root_prims;
+	const DevRootShade* root_shade;
+	const DevXform* xforms;
 	const DevFrame* frames;
+	const Mat16* frame_winv;
+	const Mat16* frame_w;
 	const float4* nodes;      // 4 float4 per node
 	const float4* tris;       // 3 float4 per triangle: (v0, e1.x) (e1.yz, e2.xy) (e2.z, id, -, -)
 	const float4* prim_info;  // per prim id: (n.x, n.y, n.z, bits(material | levels_in << 16))
 	const float4* materials;  // 4 float4 per material: (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
 	const float4* lights;     // 2 float4 per light: (pos, -) (intensity, -)
+	// the same tables once more, for the wave-uniform reads (kload)
+	PTX_KPTR(DevRootPrim) root_prims_k;
+	PTX_KPTR(DevXform) xforms_k;
+	PTX_KPTR(DevFrame) frames_k;
+	PTX_KPTR(Mat16) frame_winv_k;
+	PTX_KPTR(float4) lights_k;
 	int32_t n_root_prims, n_frames, n_lights, n_prims;
+	int32_t has_plain_sphere;
 	float ambient[3];
 	float root_min[3], root_max[3];
 };
@@ -99,14 +146,32 @@ struct Hit {
 	int32_t slot;   // root leaf: index into root_prims
 };
 
-struct Counters {  // cumulative over one ptx_render_accumulate
+struct Counters {  // cumulative over one ptx_render_accumulate (filled by k_stats_reduce)
 	unsigned long long trace_rays, shadow_rays, shaded_hits, overflow;
 	unsigned long long per_depth[kMaxDepthSlots];
 	unsigned long long per_depth_shadow[kMaxDepthSlots];
 	unsigned long long per_depth_hits[kMaxDepthSlots];
 };
+// Work counters are kept per wave: stat[(depth_slot * kStatWaves + wave) * 4 + {trace, shadow,
+// hits}], each wave adding to its own words with plain loads and stores.  Thousands of waves
+// adding to ONE word with atomics serialise at the memory side (about 10 ns per add), which
+// costs more than the rays they count; a wave's own words are touched by nobody else during
+// a launch, and launches on one stream run in order.
+constexpr unsigned kStatWaves = 16384;
+constexpr size_t kStatBytes = (size_t) kMaxDepthSlots * kStatWaves * 4 * sizeof(unsigned long long);
 
 __device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+
+// Wave-uniform read of a small read-only record: the scene tables are never written while a
+// kernel runs, so the kernel reads them through pointers in the constant address space,
+// i.e. with scalar loads into SGPRs (one s_load_dwordx16 for a 64-B record) instead of 64
+// identical vector loads.  The address MUST be the same in every lane.
+template <class T>
+__device__ __forceinline__ T kload(PTX_KPTR(T) p) {
+	T v;
+	__builtin_memcpy(&v, p, sizeof(T));
+	return v;
+}
 
 // ---------------------------------------------------------------------------
 // BVH walk.  The node test is a conservative filter (boxes are padded at build time and
@@ -131,7 +196,7 @@ __device__ __forceinline__ void bvh_slab2(float4 q0, float4 q1, float4 q2, f3 in
 }
 
 __device__ __forceinline__ float bvh_rcp(float d) {
-	float r = 1.0f / d;
+	float r = __builtin_amdgcn_rcpf(d);
 	return fabsf(r) > 1e18f ? copysignf(1e18f, r) : r;
 }
 
@@ -139,10 +204,8 @@ __device__ __forceinline__ float bvh_rcp(float d) {
 __device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0f * kEps + 1e-5f * fabsf(best_t)); }
 
 template <bool ANY>
-__device__ __forceinline__ bool bvh_walk(const DevScene& S, const DevFrame& F, int frame, f3 o, f3 d, int* __restrict__ stk, Hit& best,
-                                         float range) {
-	const float4* __restrict__ nodes = S.nodes + F.node_base;
-	const float4* __restrict__ tris = S.tris + F.tri_base;
+__device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const float4* __restrict__ tris, int bvh_root, int frame, f3 o, f3 d,
+                                         int* __restrict__ stk, Hit& best, float range) {
 	// Reciprocal direction for the node tests only.  A zero (or denormal-small) component
 	// would give inf and then inf - inf = NaN inside the fused slab test, which fminf/fmaxf
 	// would read as "no constraint on the wrong side"; a huge finite reciprocal keeps the
@@ -150,7 +213,7 @@ __device__ __forceinline__ bool bvh_walk(const DevScene& S, const DevFrame& F, i
 	f3 inv = {bvh_rcp(d.x), bvh_rcp(d.y), bvh_rcp(d.z)};
 	f3 noi = {-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)};
 	int sp = 0;
-	int cur = F.bvh_root;
+	int cur = bvh_root;
 	float limit = ANY ? cull_limit(range) : cull_limit(best.t);
 	while (true) {
 		if (cur >= 0) {
@@ -207,13 +270,54 @@ __device__ __forceinline__ bool bvh_walk(const DevScene& S, const DevFrame& F, i
 	return false;
 }
 
-// one leaf of frame 0 against a frame-0-space ray: the reference's per-shape intersect
-// up to the distance
-__device__ __forceinline__ bool root_prim_t(const DevRootPrim& P, f3 o, f3 d, float& t) {
-	f3 lo = xform_point(P.winv, o), ld = xform_dir(P.winv, d);
-	if (P.kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
-	if (P.kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
+// Per-ray values every test in frame-0 space shares.  They are the same IEEE operations the
+// reference performs inside each Box / Sphere test (1 / d.x ..., normalize(d), length(d)),
+// formed once: a shape whose transform is a pure translation sees the ray's direction
+// unchanged, so its reciprocals, unit vector and length are these very numbers.
+struct RayPre {
+	f3 inv;   // 1.0f / d
+	f3 dn;    // normalize(d)      (only when the scene holds a translated-only sphere)
+	float len;  // length(d)
+};
+__device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 d) {
+	RayPre r;
+	r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	r.dn = mk(0, 0, 0);
+	r.len = 0;
+	if (S.has_plain_sphere) {
+		r.dn = normalize(d);
+		r.len = length(d);
+	}
+	return r;
+}
+
+// one leaf of frame 0 against a frame-0-space ray: the reference's per-shape intersect up
+// to the distance.  (1*x + 0*y) + (0*z + t*1) == x + t for finite operands, so a
+// translated-only shape gets its local origin with one addition per component.
+__device__ __forceinline__ bool root_prim_t(const DevScene& S, const DevRootPrim& P, f3 o, f3 d, const RayPre& pre, float& t) {
+	const int kind = P.kind_flags & 0xff;
+	if (P.kind_flags & kPlain) {
+		f3 lo = o + ld3(P.tinv);
+		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
+		if (kind == PTX_BOX) return box_slab_inv(ld3(P.p), ld3(P.p + 3), lo, d, pre.inv, t);
+		return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, d, t);
+	}
+	const Mat16 Wi = kload(reinterpret_cast<PTX_KPTR(Mat16)>(S.xforms_k + P.xform));
+	f3 lo = xform_point(Wi.m, o), ld = xform_dir(Wi.m, d);
+	if (kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
+	if (kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
 	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
+}
+
+__device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, int f, f3 o, f3 d, f3& lo, f3& ld) {
+	if (F.plain) {
+		lo = o + ld3(F.tinv);
+		ld = d;
+	} else {
+		const Mat16 Wi = kload(S.frame_winv_k + f);
+		lo = xform_point(Wi.m, o);
+		ld = xform_dir(Wi.m, d);
+	}
 }
 
 // scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103
@@ -223,25 +327,31 @@ __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int
 	best.frame = 0;
 	best.slot = 0;
 	float unused;
-	if (!box_slab(ld3(S.root_min), ld3(S.root_max), o, d, unused)) return;
+	RayPre pre = ray_pre(S, d);
+	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return;
+#if defined(PTX_EXP_TRACE) && PTX_EXP_TRACE == 1
+	best.t = unused;
+	return;
+#endif
 	for (int i = 0; i < S.n_root_prims; ++i) {
-		const DevRootPrim& P = S.root_prims[i];
+		const DevRootPrim P = kload(S.root_prims_k + i);
 		float t;
-		if (root_prim_t(P, o, d, t)) {
-			if (t < best.t || (t == best.t && P.id < best.id)) {
-				best.t = t;
-				best.id = P.id;
-				best.frame = 0;
-				best.slot = i;
-			}
-		}
+		const bool hit = root_prim_t(S, P, o, d, pre, t);
+		const bool better = hit && (t < best.t || (t == best.t && P.id < best.id));
+		best.t = better ? t : best.t;
+		best.id = better ? P.id : best.id;
+		best.slot = better ? i : best.slot;
 	}
+#if defined(PTX_EXP_TRACE) && PTX_EXP_TRACE == 2
+	return;
+#endif
 	for (int f = 1; f < S.n_frames; ++f) {
-		const DevFrame& F = S.frames[f];
+		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
-		if (!box_slab(ld3(F.bmin), ld3(F.bmax), o, d, unused)) continue;
-		f3 lo = xform_point(F.winv, o), ld = xform_dir(F.winv, d);
-		bvh_walk<false>(S, F, f, lo, ld, stk, best, 0.0f);
+		if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
+		f3 lo, ld;
+		frame_ray(S, F, f, o, d, lo, ld);
+		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f);
 	}
 }
 
@@ -249,17 +359,20 @@ __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int
 // lies within `range`  <=>  some leaf is hit at distance <= range.
 __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
 	float t;
-	if (!box_slab(ld3(S.root_min), ld3(S.root_max), o, d, t)) return false;
+	RayPre pre = ray_pre(S, d);
+	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, t)) return false;
 	for (int i = 0; i < S.n_root_prims; ++i) {
-		if (root_prim_t(S.root_prims[i], o, d, t) && t <= range) return true;
+		const DevRootPrim P = kload(S.root_prims_k + i);
+		if (root_prim_t(S, P, o, d, pre, t) && t <= range) return true;
 	}
 	Hit dummy;
 	for (int f = 1; f < S.n_frames; ++f) {
-		const DevFrame& F = S.frames[f];
+		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
-		if (!box_slab(ld3(F.bmin), ld3(F.bmax), o, d, t)) continue;
-		f3 lo = xform_point(F.winv, o), ld = xform_dir(F.winv, d);
-		if (bvh_walk<true>(S, F, f, lo, ld, stk, dummy, range)) return true;
+		if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, t)) continue;
+		f3 lo, ld;
+		frame_ray(S, F, f, o, d, lo, ld);
+		if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range)) return true;
 	}
 	return false;
 }
@@ -276,34 +389,41 @@ __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, con
 	int levels;
 	if (h.frame == 0) {
 		const DevRootPrim& P = S.root_prims[h.slot];
-		f3 lo = xform_point(P.winv, o), ld = xform_dir(P.winv, d);
-		if (P.kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
-			s.pos = xform_point(P.w, lo + ld * h.t);
-			s.n = normalize(s.pos - xform_point(P.w, ld3(P.p)));
+		const DevRootShade& Q = S.root_shade[h.slot];
+		const int kind = P.kind_flags & 0xff;
+		// the shape's real matrices, also for translated-only shapes: the zeros of an inverted
+		// translation carry signs, and the sign of a zero normal component follows them
+		const DevXform& X = S.xforms[P.xform];
+		f3 lo = xform_point(X.winv, o), ld = xform_dir(X.winv, d);
+		if (kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
+			s.pos = xform_point(X.w, lo + ld * h.t);
+			s.n = normalize(s.pos - xform_point(X.w, ld3(P.p)));
 			s.rdir = d;
-		} else if (P.kind == PTX_BOX) {  // framework/box.cpp:98-100
+		} else if (kind == PTX_BOX) {  // framework/box.cpp:98-100
 			f3 nl = box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t);
-			s.n = normalize(xform_dir(P.w, nl));
+			s.n = normalize(xform_dir(X.w, nl));
 			s.pos = o + d * h.t;
 			s.rdir = d;
 		} else {  // framework/triangle.cpp:86
 			s.pos = o + d * h.t;
 			s.rdir = ld;
-			s.n = xform_dir(P.w, ld3(P.n));
+			s.n = xform_dir(X.w, ld3(Q.n));
 		}
-		s.material = P.material;
-		levels = P.levels_in;
+		s.material = Q.material;
+		levels = Q.levels_in;
 	} else {
-		const DevFrame& F = S.frames[h.frame];
-		f3 lo = xform_point(F.winv, o), ld = xform_dir(F.winv, d);
+		const DevFrame& F = S.frames[h.frame];  // h.frame differs between lanes: ordinary loads
+		const float* Fwinv = S.frame_winv[h.frame].m;
+		const float* Fw = S.frame_w[h.frame].m;
+		f3 lo = xform_point(Fwinv, o), ld = xform_dir(Fwinv, d);
 		float4 info = S.prim_info[h.id];
 		int packed = __float_as_int(info.w);
 		s.material = packed & 0xffff;
 		int lin = (packed >> 16) & 0xff;
 		f3 n = {info.x, info.y, info.z};
 		for (int k = 0; k < lin; ++k) n = normalize(n);  // octants / sub-objects, identity transform
-		s.n = normalize(xform_dir(F.w, n));               // the mesh Composite itself, composite.cpp:99-100
-		s.pos = xform_point(F.w, lo + ld * h.t);
+		s.n = normalize(xform_dir(Fw, n));  // the mesh Composite itself, composite.cpp:99-100
+		s.pos = xform_point(Fw, lo + ld * h.t);
 		s.rdir = ld;  // stays in mesh-local space: Composite never maps ray_direction back
 		levels = F.levels_up;
 	}
@@ -326,7 +446,7 @@ __device__ __forceinline__ Material load_material(const DevScene& S, int i) {
 __device__ __forceinline__ f3 phong(const DevScene& S, const Surface& sf, const Material& M, int* __restrict__ stk, unsigned& n_shadow) {
 	f3 col = cmul(ld3(S.ambient), M.ka);
 	for (int l = 0; l < S.n_lights; ++l) {
-		float4 lp = S.lights[2 * l], li = S.lights[2 * l + 1];
+		const float4 lp = kload(S.lights_k + 2 * l), li = kload(S.lights_k + 2 * l + 1);
 		f3 ldir = mk(lp.x, lp.y, lp.z) - sf.pos;
 		float dist = length(ldir);
 		ldir = normalize(ldir);
@@ -485,26 +605,44 @@ struct BounceArgs {
 	DevScene S;
 	DevCamera cam;
 	RayQueue in, out;
-	const unsigned* in_count;  // rays in `in` (depth > 0), read on the device; NULL => `batch` rays from `in_offset`
-	unsigned* out_count;       // rays appended to `out`
-	unsigned out_capacity;
-	unsigned in_capacity;
-	unsigned in_offset;
+	const unsigned* in_count;  // kNQ tail counters of `in` (depth > 0), kCountPad words apart
+	unsigned* out_count;       // kNQ tail counters of `out`
+	unsigned out_subcap;       // slots per sub-queue of `out`
+	unsigned in_subcap;
+	unsigned in_offset;        // first ray (in the concatenation of the sub-queues) this launch takes
+	unsigned in_take;          // rays this launch takes from in_offset on; 0 = all of them
 	unsigned long long first;  // depth 0: first linear sample index of the batch
 	unsigned batch;            // depth 0: samples in the batch; depth > 0 with in_count == NULL: rays to take
 	unsigned ns, s0;           // samples per pixel in this render's range, first sample
 	unsigned depth;
 	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
 	float* accum;
-	Counters* counters;
+	Counters* counters;        // overflow flag only
+	unsigned long long* stat;  // per-wave work counters
 };
 
 template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	int* stk = lds_stack + threadIdx.x;
+	__shared__ unsigned pfx[kNQ + 1];  // depth > 0: first ray index of every sub-queue of `in`
 	const unsigned lane = lane_id();
-	const unsigned n = (PRIMARY || !A.in_count) ? A.batch : min(*A.in_count, A.in_capacity);
+	unsigned n = A.batch;
+	if (!PRIMARY) {
+		if (threadIdx.x < 64) {
+			unsigned c = min(A.in_count[threadIdx.x * kCountPad], A.in_subcap);
+			for (int off = 1; off < 64; off <<= 1) {
+				unsigned t = __shfl_up(c, off);
+				if (lane >= (unsigned) off) c += t;
+			}
+			pfx[lane + 1] = c;
+			if (lane == 0) pfx[0] = 0;
+		}
+		__syncthreads();
+		const unsigned total_in = pfx[kNQ];
+		const unsigned avail = total_in > A.in_offset ? total_in - A.in_offset : 0;
+		n = A.in_take ? min(A.in_take, avail) : avail;
+	}
 	const unsigned waves_per_block = kBlock / 64;
 	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * waves_per_block;
@@ -522,7 +660,17 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
 				unsigned s = A.s0 + (unsigned) (li - (unsigned long long) pix * A.ns);
 				make_primary(A.cam, pix, s, o, d);
 			} else {
-				const unsigned j = A.in_offset + i;
+				// ray index -> (sub-queue, slot): binary search over the 65 prefix sums in LDS
+				const unsigned g = A.in_offset + i;
+				unsigned lo_q = 0, hi_q = kNQ;
+#pragma unroll
+				for (int it = 0; it < 6; ++it) {
+					unsigned mid = (lo_q + hi_q) >> 1;
+					bool ge = pfx[mid] <= g;
+					lo_q = ge ? mid : lo_q;
+					hi_q = ge ? hi_q : mid;
+				}
+				const size_t j = (size_t) lo_q * A.in_subcap + (g - pfx[lo_q]);
 				float4 a = A.in.a[j], b = A.in.b[j], c = A.in.c[j];
 				o = mk(a.x, a.y, a.z);
 				d = mk(a.w, b.x, b.y);
@@ -532,10 +680,18 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
 		}
 		Hit h;
 		h.id = -1;
+#if defined(PTX_EXP_STAGE) && PTX_EXP_STAGE == 1
+		asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(d.x), "v"(d.y), "v"(d.z), "v"(pix));
+		continue;
+#endif
 		if (active) {
 			trace_closest(A.S, o, d, stk, h);
 			++cnt_trace;
 		}
+#if defined(PTX_EXP_STAGE) && PTX_EXP_STAGE == 2
+		asm volatile("" ::"v"(h.t), "v"(h.id), "v"(h.frame), "v"(h.slot));
+		continue;
+#endif
 		bool hit = active && h.id >= 0;
 		f3 contrib = {0, 0, 0};
 		Child refl, refr;
@@ -551,41 +707,80 @@ __global__ __launch_bounds__(kBlock) void k_bounce(BounceArgs A) {
 		unsigned long long m1 = __ballot(refl.live), m2 = __ballot(refr.live);
 		unsigned total = __builtin_popcountll(m1) + __builtin_popcountll(m2);
 		if (total) {
+			const unsigned q = (unsigned) (base >> 6) & (kNQ - 1);
 			unsigned slot0 = 0;
-			if (lane == 0) slot0 = atomicAdd(A.out_count, total);
+			if (lane == 0) slot0 = atomicAdd(A.out_count + q * kCountPad, total);
 			slot0 = __shfl(slot0, 0);
 			unsigned long long lt = lanes_below(lane);
 			unsigned my = slot0 + __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
+			const size_t qbase = (size_t) q * A.out_subcap;
 			if (refl.live) {
-				if (my < A.out_capacity) {
-					A.out.a[my] = make_float4(refl.o.x, refl.o.y, refl.o.z, refl.d.x);
-					A.out.b[my] = make_float4(refl.d.y, refl.d.z, refl.w.x, refl.w.y);
-					A.out.c[my] = make_float4(refl.w.z, __uint_as_float(pix), 0.f, 0.f);
+				if (my < A.out_subcap) {
+					A.out.a[qbase + my] = make_float4(refl.o.x, refl.o.y, refl.o.z, refl.d.x);
+					A.out.b[qbase + my] = make_float4(refl.d.y, refl.d.z, refl.w.x, refl.w.y);
+					A.out.c[qbase + my] = make_float4(refl.w.z, __uint_as_float(pix), 0.f, 0.f);
 				}
 				++my;
 			}
-			if (refr.live && my < A.out_capacity) {
-				A.out.a[my] = make_float4(refr.o.x, refr.o.y, refr.o.z, refr.d.x);
-				A.out.b[my] = make_float4(refr.d.y, refr.d.z, refr.w.x, refr.w.y);
-				A.out.c[my] = make_float4(refr.w.z, __uint_as_float(pix), 0.f, 0.f);
+			if (refr.live && my < A.out_subcap) {
+				A.out.a[qbase + my] = make_float4(refr.o.x, refr.o.y, refr.o.z, refr.d.x);
+				A.out.b[qbase + my] = make_float4(refr.d.y, refr.d.z, refr.w.x, refr.w.y);
+				A.out.c[qbase + my] = make_float4(refr.w.z, __uint_as_float(pix), 0.f, 0.f);
 			}
-			if (lane == 0 && slot0 + total > A.out_capacity) atomicAdd(&A.counters->overflow, 1ull);
+			if (lane == 0 && slot0 + total > A.out_subcap) atomicAdd(&A.counters->overflow, 1ull);
 		}
 	}
-	// per-wave statistics: one atomic per counter per wave
+	// per-wave statistics into the wave's own words (no atomics, see kStatWaves)
 	for (int off = 32; off > 0; off >>= 1) {
 		cnt_trace += __shfl_down(cnt_trace, off);
 		cnt_shadow += __shfl_down(cnt_shadow, off);
 		cnt_hits += __shfl_down(cnt_hits, off);
 	}
 	if (lane == 0 && cnt_trace) {
-		atomicAdd(&A.counters->trace_rays, (unsigned long long) cnt_trace);
-		atomicAdd(&A.counters->shadow_rays, (unsigned long long) cnt_shadow);
-		atomicAdd(&A.counters->shaded_hits, (unsigned long long) cnt_hits);
 		unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
-		atomicAdd(&A.counters->per_depth[slot], (unsigned long long) cnt_trace);
-		atomicAdd(&A.counters->per_depth_shadow[slot], (unsigned long long) cnt_shadow);
-		atomicAdd(&A.counters->per_depth_hits[slot], (unsigned long long) cnt_hits);
+		unsigned long long* st = A.stat + ((size_t) slot * kStatWaves + (wave % kStatWaves)) * 4;
+		if (wave < kStatWaves) {
+			st[0] += cnt_trace;
+			st[1] += cnt_shadow;
+			st[2] += cnt_hits;
+		} else {  // more waves than slots (cannot happen with the grids this file launches)
+			atomicAdd(st, (unsigned long long) cnt_trace);
+			atomicAdd(st + 1, (unsigned long long) cnt_shadow);
+			atomicAdd(st + 2, (unsigned long long) cnt_hits);
+		}
+	}
+}
+
+// sums the per-wave statistic words into the compact block the host reads
+__global__ __launch_bounds__(kBlock) void k_stats_reduce(const unsigned long long* __restrict__ stat, Counters* __restrict__ out) {
+	__shared__ unsigned long long red[kBlock * 3];
+	const unsigned depth = blockIdx.x;
+	unsigned long long a = 0, b = 0, c = 0;
+	for (unsigned w = threadIdx.x; w < kStatWaves; w += kBlock) {
+		const unsigned long long* st = stat + ((size_t) depth * kStatWaves + w) * 4;
+		a += st[0];
+		b += st[1];
+		c += st[2];
+	}
+	red[threadIdx.x] = a;
+	red[kBlock + threadIdx.x] = b;
+	red[2 * kBlock + threadIdx.x] = c;
+	__syncthreads();
+	for (unsigned s = kBlock / 2; s > 0; s >>= 1) {
+		if (threadIdx.x < s) {
+			red[threadIdx.x] += red[threadIdx.x + s];
+			red[kBlock + threadIdx.x] += red[kBlock + threadIdx.x + s];
+			red[2 * kBlock + threadIdx.x] += red[2 * kBlock + threadIdx.x + s];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		out->per_depth[depth] = red[0];
+		out->per_depth_shadow[depth] = red[kBlock];
+		out->per_depth_hits[depth] = red[2 * kBlock];
+		atomicAdd(&out->trace_rays, red[0]);
+		atomicAdd(&out->shadow_rays, red[kBlock]);
+		atomicAdd(&out->shaded_hits, red[2 * kBlock]);
 	}
 }
 
@@ -681,6 +876,15 @@ bool finite16(const float* m) {
 		if (!std::isfinite(m[i])) return false;
 	return true;
 }
+// rotation/scale part exactly the identity (zeros of either sign), bottom row (0,0,0,1):
+// such a matrix maps x to x + t with one rounding per component, like the reference's
+// (m0*x + m1*y) + (m2*z + m3*1) does when m0..m2 are unit vectors
+bool pure_translation(const float* m) {
+	for (int c = 0; c < 3; ++c)
+		for (int r = 0; r < 3; ++r)
+			if (m[c * 4 + r] != (c == r ? 1.0f : 0.0f)) return false;
+	return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f;
+}
 bool is_identity(const float* m) {
 	for (int c = 0; c < 4; ++c)
 		for (int r = 0; r < 4; ++r)
@@ -699,6 +903,7 @@ struct PtxScene {
 	uint64_t qrays = 0;      // ray slots in qmem
 	unsigned* d_counts = nullptr;  // queue counters, one per depth, each on its own 256-B line
 	Counters* d_counters = nullptr;
+	unsigned long long* d_stat = nullptr;
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
 	bool profiling = false;
@@ -817,6 +1022,8 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	// A leaf or frame whose transform holds a non-finite number can never be hit by the
 	// reference's sphere test and is dropped here for every kind.
 	std::vector<DevRootPrim> root_prims;
+	std::vector<DevRootShade> root_shade;
+	std::vector<DevXform> xforms;
 	std::vector<float4> prim_info((size_t) std::max(D->n_prims, 1));
 	std::vector<std::vector<int>> frame_tris(D->n_frames);
 	std::vector<char> frame_ok(D->n_frames, 1);
@@ -842,20 +1049,33 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			if (P.levels_in < 1) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": a root leaf sits under at least the root (levels_in >= 1)");
 			if (!finite) continue;
 			DevRootPrim R{};
-			std::memcpy(R.winv, P.world_inv, sizeof R.winv);
-			std::memcpy(R.w, P.world, sizeof R.w);
+			DevRootShade Q{};
+			const bool plain = pure_translation(P.world) && pure_translation(P.world_inv);
+			R.kind_flags = P.kind | (plain ? kPlain : 0);
+			for (int k = 0; k < 3; ++k) {
+				R.tinv[k] = P.world_inv[12 + k];
+				Q.tw[k] = P.world[12 + k];
+			}
 			std::memcpy(R.p, P.p, sizeof R.p);
 			if (P.kind == PTX_TRIANGLE)
 				for (int k = 0; k < 3; ++k) {
 					R.p[3 + k] = P.p[3 + k] - P.p[k];  // e1 = v1 - v0, framework/triangle.cpp:58
 					R.p[6 + k] = P.p[6 + k] - P.p[k];  // e2 = v2 - v0, :59
 				}
-			std::memcpy(R.n, P.normal, sizeof R.n);
-			R.kind = P.kind;
 			R.id = i;
-			R.levels_in = P.levels_in;
-			R.material = P.material;
+			{
+				DevXform X{};
+				std::memcpy(X.winv, P.world_inv, sizeof X.winv);
+				std::memcpy(X.w, P.world, sizeof X.w);
+				R.xform = (int32_t) xforms.size();
+				xforms.push_back(X);
+			}
+			if (plain && P.kind == PTX_SPHERE) sc->dev.has_plain_sphere = 1;
+			std::memcpy(Q.n, P.normal, sizeof Q.n);
+			Q.levels_in = P.levels_in;
+			Q.material = P.material;
 			root_prims.push_back(R);
+			root_shade.push_back(Q);
 		} else {
 			if (P.kind != PTX_TRIANGLE) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": only triangles may live inside a mesh frame");
 			if (!is_identity(P.world)) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": a mesh triangle must not carry its own transform");
@@ -863,16 +1083,19 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		}
 	}
 	std::vector<DevFrame> frames(D->n_frames);
+	std::vector<Mat16> frame_winv(D->n_frames), frame_w(D->n_frames);
 	std::vector<ptx::BvhNode> nodes;
 	std::vector<float4> tris;
 	for (int f = 1; f < D->n_frames; ++f) {
 		const PtxFrame& F = D->frames[f];
 		DevFrame& G = frames[f];
-		std::memcpy(G.winv, F.world_inv, sizeof G.winv);
-		std::memcpy(G.w, F.world, sizeof G.w);
+		std::memcpy(frame_winv[f].m, F.world_inv, sizeof(Mat16));
+		std::memcpy(frame_w[f].m, F.world, sizeof(Mat16));
+		for (int k = 0; k < 3; ++k) G.tinv[k] = F.world_inv[12 + k];
 		std::memcpy(G.bmin, F.bounds_min, sizeof G.bmin);
 		std::memcpy(G.bmax, F.bounds_max, sizeof G.bmax);
 		G.levels_up = F.levels_up;
+		G.plain = pure_translation(F.world) && pure_translation(F.world_inv);
 		if (F.levels_up < 1 || F.levels_up > 255) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": levels_up out of range");
 		auto const& ids = frame_tris[f];
 		G.has_prims = !ids.empty();
@@ -912,7 +1135,11 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	PtxStatus st;
 	DevScene& S = sc->dev;
 	if ((st = sc->upload(root_prims, &S.root_prims)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(root_shade, &S.root_shade)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(xforms, &S.xforms)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(frames, &S.frames)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(frame_winv, &S.frame_winv)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(frame_w, &S.frame_w)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	{
 		const ptx::BvhNode* dn = nullptr;
 		if ((st = sc->upload(nodes, &dn)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
@@ -922,6 +1149,12 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	if ((st = sc->upload(prim_info, &S.prim_info)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(mats, &S.materials)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(lights, &S.lights)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	// same addresses; copied as bits because the device pass types the *_k members differently
+	std::memcpy(&S.root_prims_k, &S.root_prims, sizeof(void*));
+	std::memcpy(&S.xforms_k, &S.xforms, sizeof(void*));
+	std::memcpy(&S.frames_k, &S.frames, sizeof(void*));
+	std::memcpy(&S.frame_winv_k, &S.frame_winv, sizeof(void*));
+	std::memcpy(&S.lights_k, &S.lights, sizeof(void*));
 	S.n_root_prims = (int) root_prims.size();
 	S.n_frames = D->n_frames;
 	S.n_lights = D->n_lights;
@@ -934,7 +1167,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	if (queue_bytes == 0) queue_bytes = 4ull << 30;
 	uint64_t cap = queue_bytes / 48;
 	cap = std::min<uint64_t>(cap, 1ull << 31);
-	cap = std::max<uint64_t>(cap, 1ull << 17);
+	cap = std::max<uint64_t>(cap, 1ull << 21);  // 96 MiB: enough for one sub-queued queue per depth at the deepest tree allowed
 	cap &= ~127ull;
 	sc->qrays = cap;
 	{
@@ -956,6 +1189,9 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		if (hipMalloc(&p, 1024) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
 		sc->d_counters = static_cast<Counters*>(p);
+		if (hipMalloc(&p, kStatBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
+		sc->allocs.push_back(p);
+		sc->d_stat = static_cast<unsigned long long*>(p);
 		static_assert(sizeof(Counters) <= 1024, "counter block");
 	}
 	*out = sc.release();
@@ -1000,6 +1236,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	camera_basis(sc->camera, *rp, A.cam);
 	A.accum = d_accum;
 	A.counters = sc->d_counters;
+	A.stat = sc->d_stat;
 	const unsigned ns = rp->sample_end - rp->sample_begin;
 	A.ns = ns;
 	A.s0 = rp->sample_begin;
@@ -1007,6 +1244,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	const unsigned max_depth = sc->bouncing ? rp->max_ray_bounces : 0;  // no material spawns rays: depth 0 only
 
 	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 1024, stream));
+	HIP_TRY(hipMemsetAsync(sc->d_stat, 0, kStatBytes, stream));
 	uint64_t launches = 0;
 	const bool prof = sc->profiling && stats;
 	sc->event_depth.clear();
@@ -1030,34 +1268,45 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		q.c = q.b + cap;
 		return q;
 	};
-	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountStride; };
+	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountsPerDepth; };
+	// most input rays a launch may take so that no sub-queue of its output can fill up: the
+	// sub-queue that gets the most steps gets ceil(steps / kNQ) of them, each at most
+	// 64 * (children per ray) rays
+	const unsigned per_step = sc->branching ? 128 : 64;
+	auto max_input = [&](uint64_t subcap) -> uint64_t {
+		uint64_t steps = subcap / per_step;
+		return steps > 1 ? (steps - 1) * kNQ * 64 : 0;
+	};
 
 	// Two ways to drive the ray tree through the queues.
 	//  (1) no host synchronisation: two ping-pong queues, and a primary batch so small that
-	//      even if every hit spawned the most children the scene's materials allow, depth
-	//      max_depth could not outgrow a queue.  Every launch reads its ray count on the device.
+	//      even if every hit spawned the most children the scene's materials allow, no depth
+	//      could outgrow a queue.  Every launch reads its ray counts on the device.
 	//  (2) when that batch would be too small to fill the GPU (deep trees of two-child
 	//      materials): one queue per depth, the rays of a depth are taken in chunks whose
-	//      children are certain to fit the next queue, and the host reads one counter per
-	//      launch to learn how many there are (depth-first over the chunks).
-	const uint64_t cap2 = (sc->qrays / 2) & ~63ull;
-	const uint64_t growth_safe = sc->branching ? (max_depth < 40 ? cap2 >> max_depth : 0) : cap2;
+	//      children are certain to fit the next queue, and the host reads the tail counters
+	//      after each launch to learn how many there are (depth-first over the chunks).
+	const uint64_t cap2 = (sc->qrays / 2) & ~(uint64_t) (kNQ * 64 - 1);
+	const uint64_t in_max2 = max_input(cap2 / kNQ);
+	uint64_t growth_safe = in_max2;
+	if (sc->branching && max_depth > 1) growth_safe = max_depth - 1 < 40 ? in_max2 >> (max_depth - 1) : 0;
 	const bool sync_free = max_depth == 0 || growth_safe >= (1u << 18);
 	if (sync_free) {
-		uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(growth_safe, 64), 1ull << 30) & ~63ull;
+		uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(max_depth == 0 ? (1u << 24) : growth_safe, 64), 1ull << 30) & ~63ull;
 		RayQueue q[2] = {queue_at(0, cap2), queue_at(cap2, cap2)};
-		A.out_capacity = A.in_capacity = (unsigned) cap2;
+		A.out_subcap = A.in_subcap = (unsigned) (cap2 / kNQ);
+		A.in_offset = 0;
+		A.in_take = 0;
 		for (uint64_t first = 0; first < total; first += batch) {
 			unsigned cnt = (unsigned) std::min<uint64_t>(batch, total - first);
-			if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountStride * sizeof(unsigned), stream));
+			if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
 			A.first = first;
 			A.batch = cnt;
 			A.depth = 0;
 			A.last_depth = (max_depth == 0);
 			A.in = q[1];
 			A.out = q[0];
-			A.in_count = nullptr;
-			A.in_offset = 0;
+			A.in_count = count_of(0);
 			A.out_count = count_of(1);
 			unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
 			HIP_TRY(tick(0, true));
@@ -1078,23 +1327,25 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 			}
 		}
 	} else {
-		const uint64_t capd = (sc->qrays / max_depth) & ~63ull;  // queue d (1..max_depth) holds the rays traced at depth d
-		const unsigned chunk = (unsigned) std::min<uint64_t>((sc->branching ? capd / 2 : capd) & ~63ull, 1u << 30);
+		const uint64_t capd = (sc->qrays / max_depth) & ~(uint64_t) (kNQ * 64 - 1);  // queue d (1..max_depth): the rays traced at depth d
+		const unsigned subcap = (unsigned) (capd / kNQ);
+		const unsigned chunk = (unsigned) std::min<uint64_t>(max_input(subcap), 1u << 30);
 		if (chunk < 64) return fail(PTX_ERR_NOMEM, "queue_bytes too small for max_ray_bounces: raise queue_bytes in ptx_scene_create");
-		A.out_capacity = A.in_capacity = (unsigned) capd;
-		A.in_count = nullptr;
-		PtxStatus rst = PTX_OK;
+		A.out_subcap = A.in_subcap = subcap;
+		std::vector<unsigned> tails(kCountsPerDepth);
 		// rays [0, n) of queue d are traced in chunks; each chunk's children go to queue d+1 and are
 		// finished (recursively) before the next chunk overwrites that queue
 		auto run = [&](auto&& self, unsigned d, unsigned n) -> PtxStatus {
 			for (unsigned off = 0; off < n; off += chunk) {
 				unsigned cnt = std::min(chunk, n - off);
 				const bool last = (d == max_depth);
-				if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountStride * sizeof(unsigned), stream));
+				if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
 				A.depth = d;
 				A.last_depth = last;
 				A.batch = cnt;
 				A.in_offset = off;
+				A.in_take = cnt;
+				A.in_count = count_of(d);
 				A.out_count = count_of(d + 1);
 				if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
 				A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
@@ -1105,17 +1356,18 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 				HIP_TRY(tick(d, false));
 				++launches;
 				if (last) continue;
-				unsigned m = 0;
-				HIP_TRY(hipMemcpyAsync(&m, count_of(d + 1), sizeof m, hipMemcpyDeviceToHost, stream));
+				HIP_TRY(hipMemcpyAsync(tails.data(), count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 				HIP_TRY(hipStreamSynchronize(stream));
-				if (m > capd) m = (unsigned) capd;  // cannot happen by construction; the overflow flag reports it
+				uint64_t m = 0;
+				for (unsigned k = 0; k < kNQ; ++k) m += std::min(tails[(size_t) k * kCountPad], subcap);  // a clipped tail raised the overflow flag
 				if (m) {
-					PtxStatus st2 = self(self, d + 1, m);
+					PtxStatus st2 = self(self, d + 1, (unsigned) m);
 					if (st2 != PTX_OK) return st2;
 				}
 			}
 			return PTX_OK;
 		};
+		PtxStatus rst = PTX_OK;
 		for (uint64_t first = 0; first < total && rst == PTX_OK; first += chunk) {
 			A.first = first;
 			rst = run(run, 0, (unsigned) std::min<uint64_t>(chunk, total - first));
@@ -1125,6 +1377,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	HIP_TRY(hipGetLastError());
 	if (check_overflow || stats) {
 		Counters c;
+		if (stats) hipLaunchKernelGGL(k_stats_reduce, dim3(kMaxDepthSlots), dim3(kBlock), 0, stream, sc->d_stat, sc->d_counters);
 		HIP_TRY(hipMemcpyAsync(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		if (stats) {

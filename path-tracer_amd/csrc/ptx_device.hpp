@@ -48,39 +48,41 @@ __device__ __forceinline__ f3 xform_dir(const float* __restrict__ M, f3 v) {
 	        (M[2] * v.x + M[6] * v.y) + (M[10] * v.z + M[14] * 0.0f)};
 }
 
-// Box::intersect(Ray, float&) of framework/box.cpp:105-165 on an already-local ray.
-__device__ __forceinline__ bool box_slab(f3 lo, f3 hi, f3 o, f3 d, float& t) {
+// The intersectors below are written WITHOUT early returns: every lane runs the whole
+// formula and the reference's `return false` conditions are OR-ed into one flag.  The
+// values that survive are computed by the same operations in the same order, so results
+// are unchanged; what changes is that a wave executes one straight block per primitive
+// instead of a ladder of exec-mask branches (a rejected lane's leftovers - inf, NaN from
+// 1/0 or sqrt(<0) - are never read).
+
+// Box::intersect(Ray, float&) of framework/box.cpp:105-165 on an already-local ray, with the
+// three reciprocals 1/d supplied (the reference forms them inside, :119, :132, :143).
+__device__ __forceinline__ bool box_slab_inv(f3 lo, f3 hi, f3 o, f3 d, f3 inv, float& t) {
+	const bool zx = (0.0f == d.x), zy = (0.0f == d.y), zz = (0.0f == d.z);
 	float t_min = -kInf, t_max = kInf;
-	if (0.0f == d.x) {
-		if (o.x < lo.x || o.x > hi.x) return false;
-	} else {
-		float inv = 1.0f / d.x;
-		float t1 = (lo.x - o.x) * inv, t2 = (hi.x - o.x) * inv;
-		t_min = smax(t_min, smin(t1, t2));
-		t_max = smin(t_max, smax(t1, t2));
+	{
+		float t1 = (lo.x - o.x) * inv.x, t2 = (hi.x - o.x) * inv.x;
+		t_min = zx ? t_min : smax(t_min, smin(t1, t2));
+		t_max = zx ? t_max : smin(t_max, smax(t1, t2));
 	}
-	if (0.0f == d.y) {
-		if (o.y < lo.y || o.y > hi.y) return false;
-	} else {
-		float inv = 1.0f / d.y;
-		float t1 = (lo.y - o.y) * inv, t2 = (hi.y - o.y) * inv;
-		t_min = smax(t_min, smin(t1, t2));
-		t_max = smin(t_max, smax(t1, t2));
+	{
+		float t1 = (lo.y - o.y) * inv.y, t2 = (hi.y - o.y) * inv.y;
+		t_min = zy ? t_min : smax(t_min, smin(t1, t2));
+		t_max = zy ? t_max : smin(t_max, smax(t1, t2));
 	}
-	if (0.0f == d.z) {
-		if (o.z < lo.z || o.z > hi.z) return false;
-	} else {
-		float inv = 1.0f / d.z;
-		float t1 = (lo.z - o.z) * inv, t2 = (hi.z - o.z) * inv;
-		t_min = smax(t_min, smin(t1, t2));
-		t_max = smin(t_max, smax(t1, t2));
+	{
+		float t1 = (lo.z - o.z) * inv.z, t2 = (hi.z - o.z) * inv.z;
+		t_min = zz ? t_min : smax(t_min, smin(t1, t2));
+		t_max = zz ? t_max : smin(t_max, smax(t1, t2));
 	}
-	if (t_max < t_min) return false;
-	if (t_min > 0.0f) t = t_min;
-	else if (t_max > 0.0f) t = t_max;
-	else return false;
-	t -= kEps;
-	return true;
+	// a ray parallel to a slab and outside it misses (:113, :128, :139)
+	const bool outside = (zx && (o.x < lo.x || o.x > hi.x)) || (zy && (o.y < lo.y || o.y > hi.y)) || (zz && (o.z < lo.z || o.z > hi.z));
+	const bool ok = !outside && !(t_max < t_min) && (t_min > 0.0f || t_max > 0.0f);
+	t = (t_min > 0.0f ? t_min : t_max) - kEps;
+	return ok;
+}
+__device__ __forceinline__ bool box_slab(f3 lo, f3 hi, f3 o, f3 d, float& t) {
+	return box_slab_inv(lo, hi, o, d, mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), t);
 }
 
 // Box::surface_normal, framework/box.cpp:167-182
@@ -95,22 +97,24 @@ __device__ __forceinline__ f3 box_face_normal(f3 lo, f3 hi, f3 p) {
 }
 
 // Sphere::intersect up to `t` (framework/sphere.cpp:35-46 + glm gtx/intersect.inl:152-170);
-// (o, d) is the ray already in the sphere's local space.
-__device__ __forceinline__ bool sphere_t(f3 c, float radius, f3 o, f3 d, float& t) {
+// o is the ray origin in the sphere's local space, dn = normalize(d_local), len = length(d_local).
+__device__ __forceinline__ bool sphere_t_pre(f3 c, float radius, f3 o, f3 dn, float len, float& t) {
 	const float feps = 1.1920928955078125e-07f;  // std::numeric_limits<float>::epsilon()
-	f3 dn = normalize(d);
 	float r2 = radius * radius;
 	f3 diff = c - o;
 	float t0 = dot(diff, dn);
 	float dsq = dot(diff, diff) - t0 * t0;
-	if (dsq > r2) return false;
+	const bool miss = dsq > r2;
 	float t1 = __builtin_sqrtf(r2 - dsq);
 	float tt = t0 > t1 + feps ? t0 - t1 : t0 + t1;
-	if (!(tt > feps)) return false;
-	tt /= length(d);
+	const bool ok = !miss && (tt > feps);
+	tt /= len;
 	tt -= kEps;
 	t = tt;
-	return true;
+	return ok;
+}
+__device__ __forceinline__ bool sphere_t(f3 c, float radius, f3 o, f3 d, float& t) {
+	return sphere_t_pre(c, radius, o, normalize(d), length(d), t);
 }
 
 // Triangle::intersect up to `t` (framework/triangle.cpp:56-85) with e1 = v1 - v0 and
@@ -118,18 +122,18 @@ __device__ __forceinline__ bool sphere_t(f3 c, float radius, f3 o, f3 d, float& 
 __device__ __forceinline__ bool tri_t(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float& t) {
 	f3 p = cross(d, e2);
 	float det = dot(e1, p);
-	if (det < kEps && det > -kEps) return false;
+	const bool parallel = det < kEps && det > -kEps;
 	float inv_det = 1.0f / det;
 	f3 tv = o - v0;
 	float u = dot(tv, p) * inv_det;
-	if (u < 0.0f || u > 1.0f) return false;
+	const bool bad_u = u < 0.0f || u > 1.0f;
 	f3 q = cross(tv, e1);
 	float v = dot(d, q) * inv_det;
-	if (v < 0.0f || u + v > 1.0f) return false;
+	const bool bad_v = v < 0.0f || u + v > 1.0f;
 	float tt = dot(e2, q) * inv_det;
-	if (tt < kEps) return false;
+	const bool bad_t = tt < kEps;
 	t = tt - kEps;
-	return true;
+	return !(parallel || bad_u || bad_v || bad_t);
 }
 
 // Renderer::schlick_reflection_ratio, framework/renderer.cpp:252-276

@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of library builds on the bench workload at reduced spp: [SCENE=x.sdf] scripts/ab.sh <aa> <lib>...
+AA=$1; shift
+SCENE=${SCENE:-example.sdf}
+for lib in "$@"; do
+  for rep in 1 2; do
+    PTX_LIB=$lib timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --aa $AA --scene $SCENE 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print('$lib $SCENE', 'Msamples/s %.0f' % d['value'], 'ms/step %.1f' % d['ms_per_step'], 'rays/sample %.2f' % d['work']['rays_per_sample'], 'depth ms', d['kernel_time']['per_depth_ms'])"
+  done
+done
