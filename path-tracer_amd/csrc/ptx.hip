@@ -460,14 +460,20 @@ __device__ __forceinline__ f3 phong(const DevScene& S, const Surface& sf, const 
 			f3 r = 2 * dot(sf.n, ldir) * sf.n - ldir;
 			float cs = dot(r, sf.rdir * -1.0f);
 			if (!(cs < 0.0f)) {
+#if defined(PTX_EXP_SHADE) && PTX_EXP_SHADE == 1
+				float f = cs * M.m;
+#else
 				float f = (float) pow((double) cs, (double) M.m);
+#endif
 				spec = cmul(I, M.ks) * f;
 			}
 			has_spec = true;
 		}
 		if (!any_nonzero(diffuse) && !any_nonzero(spec)) continue;
 		++n_shadow;
+#if !(defined(PTX_EXP_SHADE) && PTX_EXP_SHADE == 2)
 		if (trace_any(S, sf.pos, ldir, dist, stk)) continue;
+#endif
 		col = col + diffuse;
 		if (has_spec) col = col + spec;
 	}
@@ -701,7 +707,11 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 			contrib = shade(A.S, sf, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
 			++cnt_hits;
 		}
+#if defined(PTX_EXP_SHADE) && PTX_EXP_SHADE == 3
+		asm volatile("" ::"v"(contrib.x), "v"(contrib.y), "v"(contrib.z));
+#else
 		accumulate(A.accum, pix, contrib, hit);
+#endif
 
 		// wave64 ballot compaction of the child rays: a lane's two children stay adjacent
 		unsigned long long m1 = __ballot(refl.live), m2 = __ballot(refr.live);
