@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration; 0 skips it")
     ap.add_argument("--cpu-kind", choices=["port", "reference"], default="port")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel launches with HIP events")
+    ap.add_argument("--pipeline", choices=["default", "fused", "staged"], default="default")
     ap.add_argument("--save-ppm", default=None)
+    ap.add_argument("--verify", action="store_true", help="rank 0 also renders all samples alone and reports the max abs difference")
     return ap.parse_args()
 
 
@@ -85,13 +87,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PTX_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank code
+    # on a one-GPU box (RCCL refuses two ranks on one device); the real runs use nccl = RCCL.
+    backend = os.environ.get("PTX_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    local_rank = device_index
 
     scene_path = os.path.join(pt.SDF_DIR, args.scene)
     host = pt.HostScene(scene_path)
@@ -102,7 +109,7 @@ def main():
     w, h, aa, nb = args.width, args.height, args.aa, args.bounces
     spp = aa * aa
     s0, s1 = ptdist.sample_range(rank, world, spp)
-    rp = pt.render_params(w, h, aa, nb, s0, s1)
+    rp = pt.render_params(w, h, aa, nb, s0, s1, args.pipeline)
     accum = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
     color = torch.empty(w * h * 3, dtype=torch.float32, device=dev) if rank == 0 else None
     rgb = torch.empty(w * h * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -155,25 +162,47 @@ def main():
                        "algorithmic_bytes_per_sample": (BYTES_PER_RAY * R + BYTES_PER_HIT * H) / my_samples,
                        "Mrays/s": R * world * args.steps / elapsed / 1e6 if world == 1 else None,
                        "kernel_launches_per_step": stats["launches"]}
-        if profile and stats["per_depth_launches"][0]:
-            n0 = stats["per_depth_launches"][0]
-            ms0 = stats["per_depth_ms"][0]
-            bytes0 = BYTES_PER_RAY * (stats["per_depth_rays"][0] + stats["per_depth_shadow"][0]) + BYTES_PER_HIT * stats["per_depth_hits"][0]
+        kms, kln = stats["kernel_ms"], stats["kernel_launches"]
+        if profile and kln[0][0]:
+            # dominant kernel = the depth-0 launch of kernel kind 0: the fused bounce kernel, or
+            # (staged pipeline) the closest-hit kernel.  Its algorithmic bytes: fused = every ray
+            # segment it handles (primary + its shadow rays) and every hit it shades; staged
+            # closest-hit kernel = its share of a ray segment: ray record read + hit record written.
+            n0, ms0 = kln[0][0], kms[0][0]
+            staged = kln[1][0] > 0
+            rays0, shadow0, hits0 = stats["per_depth_rays"][0], stats["per_depth_shadow"][0], stats["per_depth_hits"][0]
+            if staged:
+                name = "k_trace<true> (depth 0: ray generation + closest hit -> hit records)"
+                bytes0 = (48 + 16) * rays0
+            else:
+                name = "k_bounce<true> (depth 0: ray generation + closest hit + shading + shadow + emit + accumulate)"
+                bytes0 = BYTES_PER_RAY * (rays0 + shadow0) + BYTES_PER_HIT * hits0
             achieved = bytes0 / (ms0 * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_bounce<true> (depth 0: ray generation + closest hit + shading + shadow + emit + accumulate)",
-                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "launches": n0, "avg_launch_ms": ms0 / n0, "algorithmic_bytes_per_launch": bytes0 / n0}
-            tot_ms = sum(stats["per_depth_ms"])
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n0, "avg_launch_ms": ms0 / n0,
+                               "algorithmic_bytes_per_launch": bytes0 / n0}
+            tot_ms = sum(sum(r) for r in kms)
             tot_bytes = BYTES_PER_RAY * R + BYTES_PER_HIT * H
-            out["kernel_time"] = {"per_depth_ms": [round(x, 3) for x in stats["per_depth_ms"][: nb + 1]],
+            out["kernel_time"] = {"pipeline": "staged" if staged else "fused",
+                                  "closest_hit_or_fused_ms_per_depth": [round(x, 3) for x in kms[0][: nb + 1]],
+                                  "shade_ms_per_depth": [round(x, 3) for x in kms[1][: nb + 1]],
+                                  "shadow_ms_per_depth": [round(x, 3) for x in kms[2][: nb + 1]],
                                   "per_depth_rays": stats["per_depth_rays"][: nb + 1],
-                                  "all_bounce_launches_ms": tot_ms, "all_bounce_launches_algorithmic_GBs": tot_bytes / (tot_ms * 1e-3) / 1e9}
+                                  "all_launches_ms": tot_ms, "all_launches_algorithmic_GBs": tot_bytes / (tot_ms * 1e-3) / 1e9}
         else:
             out["roofline"] = None
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene_path)
         else:
             out["cpu_baseline"] = None
+        if args.verify:
+            # the summed image of all ranks against one rank rendering every sample alone
+            acc1 = torch.zeros_like(accum)
+            ds.render_accumulate(pt.render_params(w, h, aa, nb, pipeline=args.pipeline), acc1.data_ptr(), stream, check_overflow=True)
+            col1 = torch.empty_like(color)
+            ds.resolve(acc1.data_ptr(), w, h, spp, col1.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+            out["verify_max_abs_vs_single_rank"] = float((col1 - color).abs().max().item())
         if args.save_ppm:
             pt.write_ppm(args.save_ppm, rgb.cpu().numpy().reshape(h, w, 3))
         print(json.dumps(out), flush=True)

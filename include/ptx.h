@@ -131,7 +131,17 @@ typedef struct PtxRenderParams {
 	uint32_t aa_steps;
 	uint32_t max_ray_bounces;
 	uint32_t sample_begin, sample_end; /* 0, aa_steps*aa_steps for the whole image */
+	uint32_t pipeline;                 /* PtxPipeline; 0 = the library's default */
 } PtxRenderParams;
+
+/*
+ * How one depth of the ray tree is run (same rays, same arithmetic per ray either way):
+ *   FUSED   one kernel per depth: closest hit + shading + inline shadow walks + emit
+ *   STAGED  three kernels per depth: closest hit -> hit records; shading -> child rays and
+ *           shadow-ray records; shadow walk -> accumulate.  Leaner kernels (more waves per
+ *           SIMD) at the price of hit records and shadow rays going through HBM.
+ */
+typedef enum PtxPipeline { PTX_PIPELINE_DEFAULT = 0, PTX_PIPELINE_FUSED = 1, PTX_PIPELINE_STAGED = 2 } PtxPipeline;
 
 /* Work done by the last ptx_render_accumulate on this scene (whole call). */
 typedef struct PtxStats {
@@ -143,11 +153,13 @@ typedef struct PtxStats {
 	uint64_t per_depth_rays[16];    /* closest-hit queries per ray-tree depth          */
 	uint64_t per_depth_shadow[16];  /* any-hit queries issued at that depth            */
 	uint64_t per_depth_hits[16];    /* shaded hits at that depth                       */
-	/* filled only while profiling is on (ptx_scene_set_profiling): device time of the
-	 * bounce kernel per depth, from HIP events recorded around every launch on the
-	 * caller's stream, and the number of launches timed */
-	double per_depth_ms[16];
-	uint64_t per_depth_launches[16];
+	/* filled only while profiling is on (ptx_scene_set_profiling): device time per kernel
+	 * kind and depth, from HIP events recorded around every launch on the caller's
+	 * stream, and the number of launches timed */
+	/* [kind][depth]: kind 0 = the fused kernel or the closest-hit kernel, 1 = shading kernel,
+	 * 2 = shadow kernel (kinds 1 and 2 only in the staged pipeline) */
+	double kernel_ms[3][16];
+	uint64_t kernel_launches[3][16];
 } PtxStats;
 
 const char* ptx_last_error(void);

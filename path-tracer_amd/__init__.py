@@ -67,19 +67,19 @@ class PtxSceneDesc(C.Structure):
 
 class PtxRenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aa_steps", C.c_uint32), ("max_ray_bounces", C.c_uint32),
-                ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32)]
+                ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("pipeline", C.c_uint32)]
 
 
 class PtxStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("trace_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("launches", C.c_uint64), ("per_depth_rays", C.c_uint64 * 16), ("per_depth_shadow", C.c_uint64 * 16),
-                ("per_depth_hits", C.c_uint64 * 16), ("per_depth_ms", C.c_double * 16), ("per_depth_launches", C.c_uint64 * 16)]
+                ("per_depth_hits", C.c_uint64 * 16), ("kernel_ms", (C.c_double * 16) * 3), ("kernel_launches", (C.c_uint64 * 16) * 3)]
 
     def as_dict(self):
         return dict(samples=self.samples, trace_rays=self.trace_rays, shadow_rays=self.shadow_rays, shaded_hits=self.shaded_hits,
                     launches=self.launches, per_depth_rays=list(self.per_depth_rays), per_depth_shadow=list(self.per_depth_shadow),
-                    per_depth_hits=list(self.per_depth_hits), per_depth_ms=list(self.per_depth_ms),
-                    per_depth_launches=list(self.per_depth_launches))
+                    per_depth_hits=list(self.per_depth_hits), kernel_ms=[list(r) for r in self.kernel_ms],
+                    kernel_launches=[list(r) for r in self.kernel_launches])
 
 
 _libs = {}
@@ -148,10 +148,13 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None):
+PIPELINES = {"default": 0, "fused": 1, "staged": 2}
+
+
+def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None, pipeline="default"):
     if sample_end is None:
         sample_end = aa_steps * aa_steps
-    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end)
+    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end, PIPELINES[pipeline])
 
 
 class HostScene:
@@ -231,8 +234,8 @@ class DeviceScene:
         _check(self.L.ptx_scene_info(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
         return dict(n_frames=a.value, n_prims=b.value, n_bvh_nodes=c.value, max_bvh_depth=d.value, device_bytes=e.value)
 
-    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None):
-        rp = render_params(w, h, aa, bounces, sample_begin, sample_end)
+    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default"):
+        rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline)
         color = np.zeros((h, w, 3), np.float32)
         rgb = np.zeros((h, w, 3), np.uint8)
         sec = C.c_double(0)

@@ -53,7 +53,7 @@ constexpr unsigned kMaxBounces = 63;
 constexpr unsigned kNQ = 64;
 constexpr unsigned kCountPad = 32;  // words between two tail counters
 constexpr unsigned kCountsPerDepth = kNQ * kCountPad;
-constexpr size_t kCountBytes = (size_t) (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);
+constexpr size_t kCountBytes = (size_t) 2 * (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);  // ray-queue tails, then shadow-queue tails
 
 // ---------------------------------------------------------------------------
 // device scene
@@ -441,41 +441,48 @@ __device__ __forceinline__ Material load_material(const DevScene& S, int i) {
 	return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, c.y, c.z, c.w, e.x};
 }
 
-// Renderer::phong_color, framework/renderer.cpp:137-192.  A shadow query is skipped when the
-// light's term is exactly zero or back-facing: the reference traces it and then adds nothing.
+// One light's term of Renderer::phong_color (framework/renderer.cpp:142-163) without the
+// shadow test: direction and distance to the light, diffuse + specular (:177-192; pow is the
+// double overload there).  Returns false when the term adds nothing (back-facing, or
+// exactly zero), in which case the reference's shadow query cannot change the result.
+struct LightTerm {
+	f3 ldir, diffuse, spec;
+	float dist;
+	bool has_spec;
+};
+__device__ __forceinline__ bool light_term(const DevScene& S, int l, const Surface& sf, f3 kd, f3 ks, float m, LightTerm& T) {
+	const float4 lp = kload(S.lights_k + 2 * l), li = kload(S.lights_k + 2 * l + 1);
+	f3 ldir = mk(lp.x, lp.y, lp.z) - sf.pos;
+	T.dist = length(ldir);
+	ldir = normalize(ldir);
+	T.ldir = ldir;
+	float c = dot(sf.n, ldir);
+	f3 I = {li.x, li.y, li.z};
+	T.diffuse = cmul(I, kd) * c;
+	T.spec = mk(0, 0, 0);
+	T.has_spec = (m != 0.0f);
+	if (m != 0.0f && !(c < 0.0f)) {
+		f3 r = 2 * dot(sf.n, ldir) * sf.n - ldir;
+		float cs = dot(r, sf.rdir * -1.0f);
+		if (!(cs < 0.0f)) {
+			float f = (float) pow((double) cs, (double) m);
+			T.spec = cmul(I, ks) * f;
+		}
+	}
+	if (c < 0.0f) return false;
+	return any_nonzero(T.diffuse) || any_nonzero(T.spec);
+}
+
+// Renderer::phong_color with the shadow walk inline (fused pipeline)
 __device__ __forceinline__ f3 phong(const DevScene& S, const Surface& sf, const Material& M, int* __restrict__ stk, unsigned& n_shadow) {
 	f3 col = cmul(ld3(S.ambient), M.ka);
 	for (int l = 0; l < S.n_lights; ++l) {
-		const float4 lp = kload(S.lights_k + 2 * l), li = kload(S.lights_k + 2 * l + 1);
-		f3 ldir = mk(lp.x, lp.y, lp.z) - sf.pos;
-		float dist = length(ldir);
-		ldir = normalize(ldir);
-		float c = dot(sf.n, ldir);
-		if (c < 0.0f) continue;
-		f3 I = {li.x, li.y, li.z};
-		f3 diffuse = cmul(I, M.kd) * c;
-		f3 spec = {0, 0, 0};
-		bool has_spec = false;
-		if (M.m != 0.0f) {  // specular_color, :177-192; pow is the double overload there
-			f3 r = 2 * dot(sf.n, ldir) * sf.n - ldir;
-			float cs = dot(r, sf.rdir * -1.0f);
-			if (!(cs < 0.0f)) {
-#if defined(PTX_EXP_SHADE) && PTX_EXP_SHADE == 1
-				float f = cs * M.m;
-#else
-				float f = (float) pow((double) cs, (double) M.m);
-#endif
-				spec = cmul(I, M.ks) * f;
-			}
-			has_spec = true;
-		}
-		if (!any_nonzero(diffuse) && !any_nonzero(spec)) continue;
+		LightTerm T;
+		if (!light_term(S, l, sf, M.kd, M.ks, M.m, T)) continue;
 		++n_shadow;
-#if !(defined(PTX_EXP_SHADE) && PTX_EXP_SHADE == 2)
-		if (trace_any(S, sf.pos, ldir, dist, stk)) continue;
-#endif
-		col = col + diffuse;
-		if (has_spec) col = col + spec;
+		if (trace_any(S, sf.pos, T.ldir, T.dist, stk)) continue;
+		col = col + T.diffuse;
+		if (T.has_spec) col = col + T.spec;
 	}
 	return col;
 }
@@ -485,33 +492,34 @@ struct Child {
 	bool live;
 };
 
-// Renderer::shade, framework/renderer.cpp:113-135, with reflection (:194-201) and
-// refraction (:203-225) turned into weighted child rays: the child's colour enters the
-// parent linearly, so weight_child = weight * (factor the reference multiplies it by).
-__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, f3 weight, bool last_depth, int* __restrict__ stk, Child& refl,
-                                    Child& refr, unsigned& n_shadow) {
-	Material M = load_material(S, sf.material);
-	f3 c = phong(S, sf, M, stk, n_shadow) * M.opacity;
+// The part of Renderer::shade after the Phong term (framework/renderer.cpp:117-134) with
+// reflection (:194-201) and refraction (:203-225) turned into weighted child rays: the
+// child's colour enters the parent linearly, so weight_child = weight * (factor the
+// reference multiplies it by).  k1 is the factor the reference applies to the local colour
+// after `phong * opacity` (1 when no case applies).
+__device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& M, f3 weight, bool last_depth, Child& refl, Child& refr,
+                                             float& k1) {
 	refl.live = false;
 	refr.live = false;
-	if (last_depth) return cmul(weight, c);
+	k1 = 1.0f;
+	if (last_depth) return;
 
 	float w_refl = 0.0f, w_refr = 0.0f;  // scalar factors on reflection()*ks and refraction()*kd
 	bool want_refl = false, want_refr = false;
 	if (M.glossy > 0.0f && M.opacity < 1.0f) {
 		float R = schlick(sf.rdir, sf.n, M.ior);
-		c = c * (R * M.opacity);
+		k1 = R * M.opacity;
 		w_refl = R;
 		w_refr = (1.0f - R) * (1.0f - M.opacity);
 		want_refl = want_refr = true;
 	} else if (M.glossy > 0.0f) {
 		float R = schlick(sf.rdir, sf.n, M.ior);
 		R = M.glossy + (1.0f - M.glossy) * R;
-		c = c * (1.0f - R);
+		k1 = 1.0f - R;
 		w_refl = R;
 		want_refl = true;
 	} else if (M.opacity < 1.0f) {
-		c = c * M.opacity;
+		k1 = M.opacity;
 		w_refr = 1.0f - M.opacity;
 		want_refr = true;
 	}
@@ -553,6 +561,16 @@ __device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, f3 wei
 		refl.w = wr;
 		refl.live = true;
 	}
+}
+
+// Renderer::shade for the fused pipeline: weight * (phong * opacity * k1), children out
+__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, f3 weight, bool last_depth, int* __restrict__ stk, Child& refl,
+                                    Child& refr, unsigned& n_shadow) {
+	Material M = load_material(S, sf.material);
+	f3 c = phong(S, sf, M, stk, n_shadow) * M.opacity;
+	float k1;
+	bounce_terms(sf, M, weight, last_depth, refl, refr, k1);
+	c = c * k1;
 	return cmul(weight, c);
 }
 
@@ -625,30 +643,131 @@ struct BounceArgs {
 	float* accum;
 	Counters* counters;        // overflow flag only
 	unsigned long long* stat;  // per-wave work counters
+	// staged pipeline only
+	RayQueue shadow;           // a = (o.xyz, d.x)  b = (d.yz, range, bits(pixel))  c = (contribution rgb, -)
+	unsigned* shadow_count;    // kNQ tail counters of `shadow`
+	unsigned shadow_subcap;
+	float4* hits;              // one record per input ray of the launch: (t, bits(id), bits(frame), bits(slot))
 };
 
+// number of input rays of a launch; for depth > 0 also the first ray index of every
+// sub-queue of `in` (pfx, in LDS).  All threads of the workgroup must call it.
+template <bool PRIMARY>
+__device__ __forceinline__ unsigned launch_input(const BounceArgs& A, const unsigned* in_count, unsigned in_subcap, unsigned* pfx) {
+	if (PRIMARY) return A.batch;
+	const unsigned lane = lane_id();
+	if (threadIdx.x < 64) {
+		unsigned c = min(in_count[threadIdx.x * kCountPad], in_subcap);
+		for (int off = 1; off < 64; off <<= 1) {
+			unsigned t = __shfl_up(c, off);
+			if (lane >= (unsigned) off) c += t;
+		}
+		pfx[lane + 1] = c;
+		if (lane == 0) pfx[0] = 0;
+	}
+	__syncthreads();
+	const unsigned total_in = pfx[kNQ];
+	const unsigned avail = total_in > A.in_offset ? total_in - A.in_offset : 0;
+	return A.in_take ? min(A.in_take, avail) : avail;
+}
+
+// ray index of the launch -> record index in a sub-queued queue (binary search over pfx)
+__device__ __forceinline__ size_t queue_slot(const unsigned* pfx, unsigned subcap, unsigned g) {
+	unsigned lo_q = 0, hi_q = kNQ;
+#pragma unroll
+	for (int it = 0; it < 6; ++it) {
+		unsigned mid = (lo_q + hi_q) >> 1;
+		bool ge = pfx[mid] <= g;
+		lo_q = ge ? mid : lo_q;
+		hi_q = ge ? hi_q : mid;
+	}
+	return (size_t) lo_q * subcap + (g - pfx[lo_q]);
+}
+
+// the i-th input ray of a launch: generated (depth 0, framework/renderer.cpp:76-82) or read from `in`
+template <bool PRIMARY>
+__device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* pfx, unsigned i, f3& o, f3& d, f3& w, unsigned& pix) {
+	if (PRIMARY) {
+		unsigned long long li = A.first + i;
+		pix = (unsigned) (li / A.ns);
+		unsigned s = A.s0 + (unsigned) (li - (unsigned long long) pix * A.ns);
+		make_primary(A.cam, pix, s, o, d);
+		w = mk(1, 1, 1);
+	} else {
+		const size_t j = queue_slot(pfx, A.in_subcap, A.in_offset + i);
+		float4 a = A.in.a[j], b = A.in.b[j], c = A.in.c[j];
+		o = mk(a.x, a.y, a.z);
+		d = mk(a.w, b.x, b.y);
+		w = mk(b.z, b.w, c.x);
+		pix = __float_as_uint(c.y);
+	}
+}
+
+// wave64 ballot compaction of up to two records per lane into sub-queue q of a queue: the
+// records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.
+__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned q, bool live1, const float4 r1[3],
+                                          bool live2, const float4 r2[3], Counters* counters) {
+	const unsigned lane = lane_id();
+	unsigned long long m1 = __ballot(live1), m2 = __ballot(live2);
+	unsigned total = __builtin_popcountll(m1) + __builtin_popcountll(m2);
+	if (!total) return;
+	unsigned slot0 = 0;
+	if (lane == 0) slot0 = atomicAdd(tails + q * kCountPad, total);
+	slot0 = __shfl(slot0, 0);
+	unsigned long long lt = lanes_below(lane);
+	unsigned my = slot0 + __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
+	const size_t qbase = (size_t) q * subcap;
+	if (live1) {
+		if (my < subcap) {
+			Q.a[qbase + my] = r1[0];
+			Q.b[qbase + my] = r1[1];
+			Q.c[qbase + my] = r1[2];
+		}
+		++my;
+	}
+	if (live2 && my < subcap) {
+		Q.a[qbase + my] = r2[0];
+		Q.b[qbase + my] = r2[1];
+		Q.c[qbase + my] = r2[2];
+	}
+	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);
+}
+
+__device__ __forceinline__ void pack_child(const Child& c, unsigned pix, float4 r[3]) {
+	r[0] = make_float4(c.o.x, c.o.y, c.o.z, c.d.x);
+	r[1] = make_float4(c.d.y, c.d.z, c.w.x, c.w.y);
+	r[2] = make_float4(c.w.z, __uint_as_float(pix), 0.f, 0.f);
+}
+
+__device__ __forceinline__ void wave_stats(const BounceArgs& A, unsigned wave, unsigned trace, unsigned shadow, unsigned hits) {
+	for (int off = 32; off > 0; off >>= 1) {
+		trace += __shfl_down(trace, off);
+		shadow += __shfl_down(shadow, off);
+		hits += __shfl_down(hits, off);
+	}
+	if (lane_id() == 0 && (trace | shadow | hits)) {
+		unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
+		unsigned long long* st = A.stat + ((size_t) slot * kStatWaves + (wave % kStatWaves)) * 4;
+		if (wave < kStatWaves) {
+			st[0] += trace;
+			st[1] += shadow;
+			st[2] += hits;
+		} else {  // more waves than slots (cannot happen with the grids this file launches)
+			atomicAdd(st, (unsigned long long) trace);
+			atomicAdd(st + 1, (unsigned long long) shadow);
+			atomicAdd(st + 2, (unsigned long long) hits);
+		}
+	}
+}
+
+// ---- fused pipeline: one kernel per depth -----------------------------------------------
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
+	__shared__ unsigned pfx[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
-	__shared__ unsigned pfx[kNQ + 1];  // depth > 0: first ray index of every sub-queue of `in`
 	const unsigned lane = lane_id();
-	unsigned n = A.batch;
-	if (!PRIMARY) {
-		if (threadIdx.x < 64) {
-			unsigned c = min(A.in_count[threadIdx.x * kCountPad], A.in_subcap);
-			for (int off = 1; off < 64; off <<= 1) {
-				unsigned t = __shfl_up(c, off);
-				if (lane >= (unsigned) off) c += t;
-			}
-			pfx[lane + 1] = c;
-			if (lane == 0) pfx[0] = 0;
-		}
-		__syncthreads();
-		const unsigned total_in = pfx[kNQ];
-		const unsigned avail = total_in > A.in_offset ? total_in - A.in_offset : 0;
-		n = A.in_take ? min(A.in_take, avail) : avail;
-	}
+	const unsigned n = launch_input<PRIMARY>(A, A.in_count, A.in_subcap, pfx);
 	const unsigned waves_per_block = kBlock / 64;
 	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * waves_per_block;
@@ -659,45 +778,13 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 		bool active = i < n;
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
-		if (active) {
-			if (PRIMARY) {
-				unsigned long long li = A.first + i;
-				pix = (unsigned) (li / A.ns);
-				unsigned s = A.s0 + (unsigned) (li - (unsigned long long) pix * A.ns);
-				make_primary(A.cam, pix, s, o, d);
-			} else {
-				// ray index -> (sub-queue, slot): binary search over the 65 prefix sums in LDS
-				const unsigned g = A.in_offset + i;
-				unsigned lo_q = 0, hi_q = kNQ;
-#pragma unroll
-				for (int it = 0; it < 6; ++it) {
-					unsigned mid = (lo_q + hi_q) >> 1;
-					bool ge = pfx[mid] <= g;
-					lo_q = ge ? mid : lo_q;
-					hi_q = ge ? hi_q : mid;
-				}
-				const size_t j = (size_t) lo_q * A.in_subcap + (g - pfx[lo_q]);
-				float4 a = A.in.a[j], b = A.in.b[j], c = A.in.c[j];
-				o = mk(a.x, a.y, a.z);
-				d = mk(a.w, b.x, b.y);
-				w = mk(b.z, b.w, c.x);
-				pix = __float_as_uint(c.y);
-			}
-		}
+		if (active) input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
 		Hit h;
 		h.id = -1;
-#if defined(PTX_EXP_STAGE) && PTX_EXP_STAGE == 1
-		asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(d.x), "v"(d.y), "v"(d.z), "v"(pix));
-		continue;
-#endif
 		if (active) {
 			trace_closest(A.S, o, d, stk, h);
 			++cnt_trace;
 		}
-#if defined(PTX_EXP_STAGE) && PTX_EXP_STAGE == 2
-		asm volatile("" ::"v"(h.t), "v"(h.id), "v"(h.frame), "v"(h.slot));
-		continue;
-#endif
 		bool hit = active && h.id >= 0;
 		f3 contrib = {0, 0, 0};
 		Child refl, refr;
@@ -707,57 +794,143 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 			contrib = shade(A.S, sf, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
 			++cnt_hits;
 		}
-#if defined(PTX_EXP_SHADE) && PTX_EXP_SHADE == 3
-		asm volatile("" ::"v"(contrib.x), "v"(contrib.y), "v"(contrib.z));
-#else
 		accumulate(A.accum, pix, contrib, hit);
-#endif
+		float4 r1[3], r2[3];
+		pack_child(refl, pix, r1);
+		pack_child(refr, pix, r2);
+		emit_pair(A.out, A.out_count, A.out_subcap, (unsigned) (base >> 6) & (kNQ - 1), refl.live, r1, refr.live, r2, A.counters);
+	}
+	wave_stats(A, wave, cnt_trace, cnt_shadow, cnt_hits);
+}
 
-		// wave64 ballot compaction of the child rays: a lane's two children stay adjacent
-		unsigned long long m1 = __ballot(refl.live), m2 = __ballot(refr.live);
-		unsigned total = __builtin_popcountll(m1) + __builtin_popcountll(m2);
-		if (total) {
-			const unsigned q = (unsigned) (base >> 6) & (kNQ - 1);
-			unsigned slot0 = 0;
-			if (lane == 0) slot0 = atomicAdd(A.out_count + q * kCountPad, total);
-			slot0 = __shfl(slot0, 0);
-			unsigned long long lt = lanes_below(lane);
-			unsigned my = slot0 + __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
-			const size_t qbase = (size_t) q * A.out_subcap;
-			if (refl.live) {
-				if (my < A.out_subcap) {
-					A.out.a[qbase + my] = make_float4(refl.o.x, refl.o.y, refl.o.z, refl.d.x);
-					A.out.b[qbase + my] = make_float4(refl.d.y, refl.d.z, refl.w.x, refl.w.y);
-					A.out.c[qbase + my] = make_float4(refl.w.z, __uint_as_float(pix), 0.f, 0.f);
-				}
-				++my;
-			}
-			if (refr.live && my < A.out_subcap) {
-				A.out.a[qbase + my] = make_float4(refr.o.x, refr.o.y, refr.o.z, refr.d.x);
-				A.out.b[qbase + my] = make_float4(refr.d.y, refr.d.z, refr.w.x, refr.w.y);
-				A.out.c[qbase + my] = make_float4(refr.w.z, __uint_as_float(pix), 0.f, 0.f);
-			}
-			if (lane == 0 && slot0 + total > A.out_subcap) atomicAdd(&A.counters->overflow, 1ull);
-		}
+// ---- staged pipeline: closest hit / shading / shadow rays as three lean kernels ---------
+// (k_trace needs no shading state and k_shade no traversal state, so each fits twice the
+//  waves per SIMD of the fused kernel; the price is the hit record and the shadow rays
+//  going through HBM)
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
+	__shared__ int lds_stack[kStack * kBlock];
+	__shared__ unsigned pfx[kNQ + 1];
+	int* stk = lds_stack + threadIdx.x;
+	const unsigned lane = lane_id();
+	const unsigned n = launch_input<PRIMARY>(A, A.in_count, A.in_subcap, pfx);
+	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const unsigned n_waves = gridDim.x * (kBlock / 64);
+	unsigned cnt_trace = 0;
+	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
+		unsigned i = (unsigned) base + lane;
+		if (i >= n) continue;
+		f3 o, d, w;
+		unsigned pix;
+		input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+		Hit h;
+		trace_closest(A.S, o, d, stk, h);
+		++cnt_trace;
+		A.hits[i] = make_float4(h.t, __int_as_float(h.id), __int_as_float(h.frame), __int_as_float(h.slot));
 	}
-	// per-wave statistics into the wave's own words (no atomics, see kStatWaves)
-	for (int off = 32; off > 0; off >>= 1) {
-		cnt_trace += __shfl_down(cnt_trace, off);
-		cnt_shadow += __shfl_down(cnt_shadow, off);
-		cnt_hits += __shfl_down(cnt_hits, off);
-	}
-	if (lane == 0 && cnt_trace) {
-		unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
-		unsigned long long* st = A.stat + ((size_t) slot * kStatWaves + (wave % kStatWaves)) * 4;
-		if (wave < kStatWaves) {
-			st[0] += cnt_trace;
-			st[1] += cnt_shadow;
-			st[2] += cnt_hits;
-		} else {  // more waves than slots (cannot happen with the grids this file launches)
-			atomicAdd(st, (unsigned long long) cnt_trace);
-			atomicAdd(st + 1, (unsigned long long) cnt_shadow);
-			atomicAdd(st + 2, (unsigned long long) cnt_hits);
+	wave_stats(A, wave, cnt_trace, 0, 0);
+}
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
+	__shared__ unsigned pfx[kNQ + 1];
+	const unsigned lane = lane_id();
+	const unsigned n = launch_input<PRIMARY>(A, A.in_count, A.in_subcap, pfx);
+	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const unsigned n_waves = gridDim.x * (kBlock / 64);
+	unsigned cnt_shadow = 0, cnt_hits = 0;
+	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
+		unsigned i = (unsigned) base + lane;
+		bool active = i < n;
+		Hit h;
+		h.id = -1;
+		if (active) {
+			float4 hr = A.hits[i];
+			h.t = hr.x;
+			h.id = __float_as_int(hr.y);
+			h.frame = __float_as_int(hr.z);
+			h.slot = __float_as_int(hr.w);
 		}
+		const bool hit = active && h.id >= 0;
+		if (__ballot(hit) == 0) continue;  // the whole step missed: nothing to shade, nothing to emit
+		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
+		unsigned pix = 0;
+		if (active) input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+		Surface sf;
+		sf.pos = sf.n = sf.rdir = mk(0, 0, 0);
+		f3 kd = {0, 0, 0}, ks = {0, 0, 0}, ws = {0, 0, 0};
+		float mm = 0.0f, scale0 = 0.0f, k1 = 1.0f;
+		f3 contrib = {0, 0, 0};
+		Child refl, refr;
+		refl.live = refr.live = false;
+		if (hit) {
+			sf = surface_of(A.S, o, d, h);
+			Material M = load_material(A.S, sf.material);
+			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
+			kd = M.kd;
+			ks = M.ks;
+			mm = M.m;
+			scale0 = M.opacity;
+			ws = w;
+			// ambient part of phong_color (renderer.cpp:140), scaled like the whole local colour
+			contrib = cmul(w, (cmul(ld3(A.S.ambient), M.ka) * M.opacity) * k1);
+			++cnt_hits;
+		}
+		accumulate(A.accum, pix, contrib, hit);
+		const unsigned q = (unsigned) (base >> 6) & (kNQ - 1);
+		// one shadow ray per light whose term can add something; its record carries the finished
+		// contribution weight * ((diffuse + specular) * opacity * k1)
+		for (int l = 0; l < A.S.n_lights; ++l) {
+			bool want = false;
+			float4 r[3];
+			if (hit) {
+				LightTerm T;
+				want = light_term(A.S, l, sf, kd, ks, mm, T);
+				f3 term = T.diffuse;
+				if (T.has_spec) term = term + T.spec;
+				f3 c = cmul(ws, (term * scale0) * k1);
+				r[0] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, T.ldir.x);
+				r[1] = make_float4(T.ldir.y, T.ldir.z, T.dist, __uint_as_float(pix));
+				r[2] = make_float4(c.x, c.y, c.z, 0.f);
+			}
+			if (want) ++cnt_shadow;
+			emit_pair(A.shadow, A.shadow_count, A.shadow_subcap, q, want, r, false, r, A.counters);
+		}
+		float4 r1[3], r2[3];
+		pack_child(refl, pix, r1);
+		pack_child(refr, pix, r2);
+		emit_pair(A.out, A.out_count, A.out_subcap, q, refl.live, r1, refr.live, r2, A.counters);
+	}
+	wave_stats(A, wave, 0, cnt_shadow, cnt_hits);
+}
+
+// find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
+// unblocked ray adds its contribution to its pixel
+__global__ __launch_bounds__(kBlock) void k_shadow(BounceArgs A) {
+	__shared__ int lds_stack[kStack * kBlock];
+	__shared__ unsigned pfx[kNQ + 1];
+	int* stk = lds_stack + threadIdx.x;
+	const unsigned lane = lane_id();
+	BounceArgs B = A;
+	B.in_offset = 0;
+	B.in_take = 0;
+	const unsigned n = launch_input<false>(B, A.shadow_count, A.shadow_subcap, pfx);
+	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	const unsigned n_waves = gridDim.x * (kBlock / 64);
+	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
+		unsigned i = (unsigned) base + lane;
+		bool active = i < n;
+		unsigned pix = 0;
+		f3 c = {0, 0, 0};
+		bool lit = false;
+		if (active) {
+			const size_t j = queue_slot(pfx, A.shadow_subcap, i);
+			float4 a = A.shadow.a[j], b = A.shadow.b[j], cc = A.shadow.c[j];
+			pix = __float_as_uint(b.w);
+			c = mk(cc.x, cc.y, cc.z);
+			lit = !trace_any(A.S, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), b.z, stk);
+		}
+		accumulate(A.accum, pix, c, lit);
 	}
 }
 
@@ -918,7 +1091,7 @@ struct PtxScene {
 	bool bouncing = false;   // some material spawns any child
 	bool profiling = false;
 	std::vector<hipEvent_t> events;      // pairs, reused from call to call
-	std::vector<unsigned> event_depth;   // depth of pair k
+	std::vector<unsigned> event_tag;     // kernel kind and depth of pair k
 	int n_prims = 0, n_frames = 0, n_nodes = 0, max_depth = 0, grid = 0;
 	uint64_t device_bytes = 0;
 
@@ -966,6 +1139,7 @@ PtxStatus check_params(const PtxRenderParams* p) {
 	if (p->sample_begin > p->sample_end || p->sample_end > p->aa_steps * p->aa_steps)
 		return fail(PTX_ERR_INVALID, "sample range outside [0, aa_steps^2]");
 	if (p->max_ray_bounces > kMaxBounces) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must not exceed 63");
+	if (p->pipeline > PTX_PIPELINE_STAGED) return fail(PTX_ERR_INVALID, "unknown pipeline");
 	return PTX_OK;
 }
 
@@ -1257,10 +1431,12 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	HIP_TRY(hipMemsetAsync(sc->d_stat, 0, kStatBytes, stream));
 	uint64_t launches = 0;
 	const bool prof = sc->profiling && stats;
-	sc->event_depth.clear();
-	auto tick = [&](unsigned depth, bool begin) -> hipError_t {
+	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED;  // the default is the fused pipeline (the faster one on the measured scenes)
+	sc->event_tag.clear();
+	// profiling: a pair of events around every launch; tag = kind * kMaxDepthSlots + depth slot
+	auto tick = [&](unsigned kind, unsigned depth, bool begin) -> hipError_t {
 		if (!prof) return hipSuccess;
-		size_t k = sc->event_depth.size() * 2 + (begin ? 0 : 1);
+		size_t k = sc->event_tag.size() * 2 + (begin ? 0 : 1);
 		while (sc->events.size() <= k) {
 			hipEvent_t e;
 			hipError_t err = hipEventCreate(&e);
@@ -1268,7 +1444,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 			sc->events.push_back(e);
 		}
 		hipError_t err = hipEventRecord(sc->events[k], stream);
-		if (!begin) sc->event_depth.push_back(depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1);
+		if (!begin) sc->event_tag.push_back(kind * kMaxDepthSlots + (depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1));
 		return err;
 	};
 	auto queue_at = [&](uint64_t first_slot, uint64_t cap) {
@@ -1279,13 +1455,57 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		return q;
 	};
 	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountsPerDepth; };
-	// most input rays a launch may take so that no sub-queue of its output can fill up: the
+	auto shadow_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (kMaxBounces + 2 + depth) * kCountsPerDepth; };
+	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
+	auto launch_depth = [&](unsigned d, unsigned grid) -> PtxStatus {
+		if (!staged) {
+			HIP_TRY(tick(0, d, true));
+			if (d == 0) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
+			else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+			HIP_TRY(tick(0, d, false));
+			launches += 1;
+			return PTX_OK;
+		}
+		A.shadow_count = shadow_count_of(d);
+		HIP_TRY(tick(0, d, true));
+		if (d == 0) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, stream, A);
+		else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+		HIP_TRY(tick(0, d, false));
+		HIP_TRY(tick(1, d, true));
+		if (d == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), 0, stream, A);
+		else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+		HIP_TRY(tick(1, d, false));
+		if (sc->dev.n_lights > 0) {
+			HIP_TRY(tick(2, d, true));
+			hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(kBlock), 0, stream, A);
+			HIP_TRY(tick(2, d, false));
+			launches += 1;
+		}
+		launches += 2;
+		return PTX_OK;
+	};
+	// most input rays a launch may take so that no sub-queue of its outputs can fill up: the
 	// sub-queue that gets the most steps gets ceil(steps / kNQ) of them, each at most
-	// 64 * (children per ray) rays
+	// 64 * (records per ray) records (children: 2 with a two-child material, else 1; shadow
+	// rays: one per light)
 	const unsigned per_step = sc->branching ? 128 : 64;
+	const unsigned per_step_shadow = 64 * (unsigned) std::max(sc->dev.n_lights, 1);
 	auto max_input = [&](uint64_t subcap) -> uint64_t {
 		uint64_t steps = subcap / per_step;
+		if (staged) steps = std::min<uint64_t>(steps, subcap / per_step_shadow);
 		return steps > 1 ? (steps - 1) * kNQ * 64 : 0;
+	};
+	// slots of one queue when the memory holds `queues` ray queues (+ shadow queue and hit
+	// records for the staged pipeline: 48 + 16 bytes more per slot)
+	auto slots_for = [&](unsigned queues) -> uint64_t {
+		uint64_t bytes = sc->qrays * 48;
+		uint64_t per_slot = 48ull * queues + (staged ? 64 : 0);
+		return (bytes / per_slot) & ~(uint64_t) (kNQ * 64 - 1);
+	};
+	auto place_staged = [&](unsigned queues, uint64_t cap) {  // shadow queue and hit records behind the ray queues
+		A.shadow = queue_at((uint64_t) queues * cap, cap);
+		A.shadow_subcap = (unsigned) (cap / kNQ);
+		A.hits = sc->qmem + ((uint64_t) queues + 1) * cap * 3;
 	};
 
 	// Two ways to drive the ray tree through the queues.
@@ -1296,51 +1516,42 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	//      materials): one queue per depth, the rays of a depth are taken in chunks whose
 	//      children are certain to fit the next queue, and the host reads the tail counters
 	//      after each launch to learn how many there are (depth-first over the chunks).
-	const uint64_t cap2 = (sc->qrays / 2) & ~(uint64_t) (kNQ * 64 - 1);
+	const uint64_t cap2 = slots_for(2);
 	const uint64_t in_max2 = max_input(cap2 / kNQ);
 	uint64_t growth_safe = in_max2;
 	if (sc->branching && max_depth > 1) growth_safe = max_depth - 1 < 40 ? in_max2 >> (max_depth - 1) : 0;
 	const bool sync_free = max_depth == 0 || growth_safe >= (1u << 18);
 	if (sync_free) {
-		uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(max_depth == 0 ? (1u << 24) : growth_safe, 64), 1ull << 30) & ~63ull;
+		uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(max_depth == 0 ? std::min<uint64_t>(in_max2, 1u << 24) : growth_safe, 64), 1ull << 30) & ~63ull;
 		RayQueue q[2] = {queue_at(0, cap2), queue_at(cap2, cap2)};
+		if (staged) place_staged(2, cap2);
 		A.out_subcap = A.in_subcap = (unsigned) (cap2 / kNQ);
 		A.in_offset = 0;
 		A.in_take = 0;
 		for (uint64_t first = 0; first < total; first += batch) {
 			unsigned cnt = (unsigned) std::min<uint64_t>(batch, total - first);
 			if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
+			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
 			A.first = first;
 			A.batch = cnt;
-			A.depth = 0;
-			A.last_depth = (max_depth == 0);
-			A.in = q[1];
-			A.out = q[0];
-			A.in_count = count_of(0);
-			A.out_count = count_of(1);
-			unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
-			HIP_TRY(tick(0, true));
-			hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
-			HIP_TRY(tick(0, false));
-			++launches;
-			for (unsigned d = 1; d <= max_depth; ++d) {
+			for (unsigned d = 0; d <= max_depth; ++d) {
 				A.depth = d;
 				A.last_depth = (d == max_depth);
-				A.in = q[(d - 1) & 1];
+				A.in = q[(d + 1) & 1];
 				A.out = q[d & 1];
 				A.in_count = count_of(d);
 				A.out_count = count_of(d + 1);
-				HIP_TRY(tick(d, true));
-				hipLaunchKernelGGL(k_bounce<false>, dim3(sc->grid), dim3(kBlock), 0, stream, A);
-				HIP_TRY(tick(d, false));
-				++launches;
+				unsigned grid = d == 0 ? (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid) : (unsigned) sc->grid;
+				PtxStatus ls = launch_depth(d, grid);
+				if (ls != PTX_OK) return ls;
 			}
 		}
 	} else {
-		const uint64_t capd = (sc->qrays / max_depth) & ~(uint64_t) (kNQ * 64 - 1);  // queue d (1..max_depth): the rays traced at depth d
+		const uint64_t capd = slots_for(max_depth);  // queue d (1..max_depth): the rays traced at depth d
 		const unsigned subcap = (unsigned) (capd / kNQ);
 		const unsigned chunk = (unsigned) std::min<uint64_t>(max_input(subcap), 1u << 30);
 		if (chunk < 64) return fail(PTX_ERR_NOMEM, "queue_bytes too small for max_ray_bounces: raise queue_bytes in ptx_scene_create");
+		if (staged) place_staged(max_depth, capd);
 		A.out_subcap = A.in_subcap = subcap;
 		std::vector<unsigned> tails(kCountsPerDepth);
 		// rays [0, n) of queue d are traced in chunks; each chunk's children go to queue d+1 and are
@@ -1350,6 +1561,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 				unsigned cnt = std::min(chunk, n - off);
 				const bool last = (d == max_depth);
 				if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
+				if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
 				A.depth = d;
 				A.last_depth = last;
 				A.batch = cnt;
@@ -1360,11 +1572,8 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 				if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
 				A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
 				unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
-				HIP_TRY(tick(d, true));
-				if (d == 0) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
-				else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, A);
-				HIP_TRY(tick(d, false));
-				++launches;
+				PtxStatus ls = launch_depth(d, grid);
+				if (ls != PTX_OK) return ls;
 				if (last) continue;
 				HIP_TRY(hipMemcpyAsync(tails.data(), count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 				HIP_TRY(hipStreamSynchronize(stream));
@@ -1403,11 +1612,12 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 				stats->per_depth_hits[k] = c.per_depth_hits[k];
 			}
 			if (prof)
-				for (size_t k = 0; k < sc->event_depth.size(); ++k) {
+				for (size_t k = 0; k < sc->event_tag.size(); ++k) {
 					float ms = 0;
 					HIP_TRY(hipEventElapsedTime(&ms, sc->events[2 * k], sc->events[2 * k + 1]));
-					stats->per_depth_ms[sc->event_depth[k]] += ms;
-					stats->per_depth_launches[sc->event_depth[k]] += 1;
+					unsigned kind = sc->event_tag[k] / kMaxDepthSlots, slot = sc->event_tag[k] % kMaxDepthSlots;
+					stats->kernel_ms[kind][slot] += ms;
+					stats->kernel_launches[kind][slot] += 1;
 				}
 		}
 		if (c.overflow)

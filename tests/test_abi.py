@@ -39,8 +39,8 @@ def test_struct_sizes_match_the_header(pt):
     assert ctypes.sizeof(pt.PtxCamera) == 10 * 4
     assert ctypes.sizeof(pt.PtxFrame) == (16 + 16 + 6 + 2) * 4
     assert ctypes.sizeof(pt.PtxPrim) == (4 + 9 + 3 + 32) * 4
-    assert ctypes.sizeof(pt.PtxRenderParams) == 6 * 4
-    assert ctypes.sizeof(pt.PtxStats) == 5 * 8 + 5 * 16 * 8
+    assert ctypes.sizeof(pt.PtxRenderParams) == 7 * 4
+    assert ctypes.sizeof(pt.PtxStats) == 5 * 8 + 3 * 16 * 8 + 2 * 3 * 16 * 8
 
 
 def test_no_device_means_loud_failure(pt, scenes):

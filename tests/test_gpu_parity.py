@@ -83,20 +83,25 @@ def test_hits_equal_oracle_many_rays(pt, port, scenes, name):
     assert np.array_equal(prim, b["rank"]) and beq(t[b["hit"]], b["t"][b["hit"]])
 
 
+PIPELINES = ["fused", "staged"]
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
 @pytest.mark.parametrize("name", SCENES)
-def test_image_equals_reference_golden(pt, scenes, name):
+def test_image_equals_reference_golden(pt, scenes, name, pipeline):
     g = load_golden(name)
     w, h, aa, nb = (int(v) for v in g["params"])
-    r = scenes.device_scene(name).render_image(w, h, aa, nb)
+    r = scenes.device_scene(name).render_image(w, h, aa, nb, pipeline=pipeline)
     assert_image_close(r["color"], g["color"], r["rgb"], g["rgb"])
     assert r["stats"]["samples"] == w * h * aa * aa
 
 
-def test_config1_image(pt, scenes):
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_config1_image(pt, scenes, pipeline):
     """BASELINE config 1 (cornell.sdf 480x320, 16 spp, 5 bounces) against the reference's PPM."""
     g = load_golden("config1_cornell_480x320_aa4")
     w, h, aa, nb = (int(v) for v in g["params"])
-    r = scenes.device_scene("cornell").render_image(w, h, aa, nb)
+    r = scenes.device_scene("cornell").render_image(w, h, aa, nb, pipeline=pipeline)
     bd = np.abs(r["rgb"].astype(int) - g["rgb"].astype(int))
     assert (bd > 0).mean() <= 1e-3 and bd.max() <= 1
 
@@ -105,9 +110,10 @@ def test_config1_image(pt, scenes):
                                             ("example_fixed", 320, 180, 2, 3), ("cornell_buster", 200, 120, 2, 5),
                                             ("superhot_colored", 256, 144, 2, 4), ("example", 1, 1, 1, 5), ("example", 7, 3, 5, 2)])
 def test_image_equals_oracle(pt, port, scenes, name, w, h, aa, nb):
-    r = scenes.device_scene(name).render_image(w, h, aa, nb)
     ref = port.render(scenes.oracle_scene(name), w, h, aa, nb)
-    assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    for pipeline in PIPELINES:
+        r = scenes.device_scene(name).render_image(w, h, aa, nb, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
 
 
 def test_drop_in_renderer_writes_the_reference_ppm(pt, scenes, tmp_path):
@@ -132,8 +138,8 @@ def test_sample_ranges_add_up(pt, scenes):
     full = ds.render_image(w, h, aa, nb)
     acc = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
-    for b, e in ((0, 5), (5, 6), (6, 16)):
-        ds.render_accumulate(pt.render_params(w, h, aa, nb, b, e), acc.data_ptr(), stream, check_overflow=True)
+    for (b, e), pipeline in zip(((0, 5), (5, 6), (6, 16)), ("staged", "fused", "staged")):
+        ds.render_accumulate(pt.render_params(w, h, aa, nb, b, e, pipeline), acc.data_ptr(), stream, check_overflow=True)
     color = torch.empty(h * w * 3, dtype=torch.float32, device="cuda:0")
     rgb = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda:0")
     ds.resolve(acc.data_ptr(), w, h, aa * aa, color.data_ptr(), rgb.data_ptr(), stream)
@@ -206,10 +212,15 @@ def test_deep_two_child_trees_in_small_queues(pt, port, tmp_path):
     for w, h, aa, nb in ((96, 96, 2, 6), (48, 48, 1, 11)):
         ref = port.render(s, w, h, aa, nb, counters=True)
         for ds in (small, big):
-            r = ds.render_image(w, h, aa, nb)
-            assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
-            assert r["stats"]["trace_rays"] > 3 * w * h * aa * aa
-    # the two strategies do the same work
-    a, b = small.render_image(96, 96, 2, 6)["stats"], big.render_image(96, 96, 2, 6)["stats"]
-    assert a["trace_rays"] == b["trace_rays"] and a["shadow_rays"] == b["shadow_rays"]
-    assert a["launches"] > b["launches"]
+            for pipeline in PIPELINES:
+                r = ds.render_image(w, h, aa, nb, pipeline=pipeline)
+                assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+                assert r["stats"]["trace_rays"] > 3 * w * h * aa * aa
+    # the two strategies and the two pipelines do the same work
+    for pipeline in PIPELINES:
+        a = small.render_image(96, 96, 2, 6, pipeline=pipeline)["stats"]
+        b = big.render_image(96, 96, 2, 6, pipeline=pipeline)["stats"]
+        assert a["trace_rays"] == b["trace_rays"] and a["shadow_rays"] == b["shadow_rays"]
+        assert a["launches"] > b["launches"]
+    f, s = big.render_image(96, 96, 2, 6, pipeline="fused")["stats"], big.render_image(96, 96, 2, 6, pipeline="staged")["stats"]
+    assert (f["trace_rays"], f["shadow_rays"], f["shaded_hits"]) == (s["trace_rays"], s["shadow_rays"], s["shaded_hits"])
