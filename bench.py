@@ -188,6 +188,8 @@ def main():
                                   "shade_ms_per_depth": [round(x, 3) for x in kms[1][: nb + 1]],
                                   "shadow_ms_per_depth": [round(x, 3) for x in kms[2][: nb + 1]],
                                   "per_depth_rays": stats["per_depth_rays"][: nb + 1],
+                                  "per_depth_hits": stats["per_depth_hits"][: nb + 1],
+                                  "per_depth_shadow_rays": stats["per_depth_shadow"][: nb + 1],
                                   "all_launches_ms": tot_ms, "all_launches_algorithmic_GBs": tot_bytes / (tot_ms * 1e-3) / 1e9}
         else:
             out["roofline"] = None

@@ -1508,90 +1508,85 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		A.hits = sc->qmem + ((uint64_t) queues + 1) * cap * 3;
 	};
 
-	// Two ways to drive the ray tree through the queues.
-	//  (1) no host synchronisation: two ping-pong queues, and a primary batch so small that
-	//      even if every hit spawned the most children the scene's materials allow, no depth
-	//      could outgrow a queue.  Every launch reads its ray counts on the device.
-	//  (2) when that batch would be too small to fill the GPU (deep trees of two-child
-	//      materials): one queue per depth, the rays of a depth are taken in chunks whose
-	//      children are certain to fit the next queue, and the host reads the tail counters
-	//      after each launch to learn how many there are (depth-first over the chunks).
-	const uint64_t cap2 = slots_for(2);
-	const uint64_t in_max2 = max_input(cap2 / kNQ);
-	uint64_t growth_safe = in_max2;
-	if (sc->branching && max_depth > 1) growth_safe = max_depth - 1 < 40 ? in_max2 >> (max_depth - 1) : 0;
-	const bool sync_free = max_depth == 0 || growth_safe >= (1u << 18);
-	if (sync_free) {
-		uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(max_depth == 0 ? std::min<uint64_t>(in_max2, 1u << 24) : growth_safe, 64), 1ull << 30) & ~63ull;
-		RayQueue q[2] = {queue_at(0, cap2), queue_at(cap2, cap2)};
-		if (staged) place_staged(2, cap2);
-		A.out_subcap = A.in_subcap = (unsigned) (cap2 / kNQ);
-		A.in_offset = 0;
-		A.in_take = 0;
-		for (uint64_t first = 0; first < total; first += batch) {
-			unsigned cnt = (unsigned) std::min<uint64_t>(batch, total - first);
-			if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
-			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
-			A.first = first;
-			A.batch = cnt;
-			for (unsigned d = 0; d <= max_depth; ++d) {
-				A.depth = d;
-				A.last_depth = (d == max_depth);
-				A.in = q[(d + 1) & 1];
-				A.out = q[d & 1];
-				A.in_count = count_of(d);
-				A.out_count = count_of(d + 1);
-				unsigned grid = d == 0 ? (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid) : (unsigned) sc->grid;
-				PtxStatus ls = launch_depth(d, grid);
-				if (ls != PTX_OK) return ls;
+	// Driving the ray tree through the queues: queue d (1..max_depth) holds the rays traced at
+	// depth d.  A launch takes at most `chunk` input rays, the number whose children (and
+	// shadow rays) are certain to fit the next queue whatever the materials do, so nothing can
+	// overflow.  Real scenes spawn far fewer children than that bound, so every depth of a
+	// primary chunk is first launched once, back to back, each launch reading its ray count on
+	// the device and taking min(count, chunk) rays; the host then reads the tail counters ONCE
+	// per primary chunk.  Only if some depth held more than `chunk` rays (deep trees of
+	// two-child materials) is its remainder traced, deepest depth first - the queues below a
+	// depth are free by then - chunk by chunk with the counts read back after every launch
+	// (depth-first over the chunks).
+	const unsigned nqueues = std::max(max_depth, 1u);
+	const uint64_t capd = slots_for(nqueues);
+	const unsigned subcap = (unsigned) std::min<uint64_t>(capd / kNQ, 1u << 25);  // 64 sub-queues of it stay below 2^32 rays
+	unsigned chunk = (unsigned) std::min<uint64_t>(max_input(subcap), 1u << 30);
+	if (max_depth == 0 && !staged) chunk = 1u << 26;  // nothing is queued at all
+	if (chunk < 64) return fail(PTX_ERR_NOMEM, "queue_bytes too small for max_ray_bounces: raise queue_bytes in ptx_scene_create");
+	if (staged) place_staged(nqueues, capd);
+	A.out_subcap = A.in_subcap = subcap;
+	std::vector<unsigned> tails((size_t) (max_depth + 1) * kCountsPerDepth);
+	auto set_depth = [&](unsigned d, unsigned off, unsigned take) {
+		const bool last = (d == max_depth);
+		A.depth = d;
+		A.last_depth = last;
+		A.in_offset = off;
+		A.in_take = take;
+		A.in_count = count_of(d);
+		A.out_count = count_of(d + 1);
+		if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
+		A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
+	};
+	auto rays_in = [&](const unsigned* t) {
+		uint64_t m = 0;
+		for (unsigned k = 0; k < kNQ; ++k) m += std::min(t[(size_t) k * kCountPad], subcap);  // a clipped tail raised the overflow flag
+		return m;
+	};
+	// rays [off0, n) of queue d in chunks; each chunk's children go to queue d+1 and are finished
+	// (recursively) before the next chunk overwrites that queue
+	auto run = [&](auto&& self, unsigned d, uint64_t off0, uint64_t n) -> PtxStatus {
+		for (uint64_t off = off0; off < n; off += chunk) {
+			unsigned cnt = (unsigned) std::min<uint64_t>(chunk, n - off);
+			const bool last = (d == max_depth);
+			if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
+			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
+			set_depth(d, (unsigned) off, cnt);
+			PtxStatus ls = launch_depth(d, (unsigned) sc->grid);
+			if (ls != PTX_OK) return ls;
+			if (last) continue;
+			HIP_TRY(hipMemcpyAsync(tails.data(), count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			uint64_t m = rays_in(tails.data());
+			if (m) {
+				PtxStatus st2 = self(self, d + 1, 0, m);
+				if (st2 != PTX_OK) return st2;
 			}
 		}
-	} else {
-		const uint64_t capd = slots_for(max_depth);  // queue d (1..max_depth): the rays traced at depth d
-		const unsigned subcap = (unsigned) (capd / kNQ);
-		const unsigned chunk = (unsigned) std::min<uint64_t>(max_input(subcap), 1u << 30);
-		if (chunk < 64) return fail(PTX_ERR_NOMEM, "queue_bytes too small for max_ray_bounces: raise queue_bytes in ptx_scene_create");
-		if (staged) place_staged(max_depth, capd);
-		A.out_subcap = A.in_subcap = subcap;
-		std::vector<unsigned> tails(kCountsPerDepth);
-		// rays [0, n) of queue d are traced in chunks; each chunk's children go to queue d+1 and are
-		// finished (recursively) before the next chunk overwrites that queue
-		auto run = [&](auto&& self, unsigned d, unsigned n) -> PtxStatus {
-			for (unsigned off = 0; off < n; off += chunk) {
-				unsigned cnt = std::min(chunk, n - off);
-				const bool last = (d == max_depth);
-				if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
-				if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
-				A.depth = d;
-				A.last_depth = last;
-				A.batch = cnt;
-				A.in_offset = off;
-				A.in_take = cnt;
-				A.in_count = count_of(d);
-				A.out_count = count_of(d + 1);
-				if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
-				A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
-				unsigned grid = (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid);
-				PtxStatus ls = launch_depth(d, grid);
-				if (ls != PTX_OK) return ls;
-				if (last) continue;
-				HIP_TRY(hipMemcpyAsync(tails.data(), count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-				HIP_TRY(hipStreamSynchronize(stream));
-				uint64_t m = 0;
-				for (unsigned k = 0; k < kNQ; ++k) m += std::min(tails[(size_t) k * kCountPad], subcap);  // a clipped tail raised the overflow flag
-				if (m) {
-					PtxStatus st2 = self(self, d + 1, (unsigned) m);
-					if (st2 != PTX_OK) return st2;
-				}
-			}
-			return PTX_OK;
-		};
-		PtxStatus rst = PTX_OK;
-		for (uint64_t first = 0; first < total && rst == PTX_OK; first += chunk) {
-			A.first = first;
-			rst = run(run, 0, (unsigned) std::min<uint64_t>(chunk, total - first));
+		return PTX_OK;
+	};
+	for (uint64_t first = 0; first < total; first += chunk) {
+		const unsigned cnt = (unsigned) std::min<uint64_t>(chunk, total - first);
+		if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
+		if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
+		A.first = first;
+		A.batch = cnt;
+		for (unsigned d = 0; d <= max_depth; ++d) {
+			set_depth(d, 0, chunk);
+			unsigned grid = d == 0 ? (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid) : (unsigned) sc->grid;
+			PtxStatus ls = launch_depth(d, grid);
+			if (ls != PTX_OK) return ls;
 		}
-		if (rst != PTX_OK) return rst;
+		if (max_depth == 0) continue;
+		HIP_TRY(hipMemcpyAsync(tails.data(), count_of(1), (size_t) max_depth * kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		std::vector<uint64_t> held(max_depth + 1, 0);
+		for (unsigned d = 1; d <= max_depth; ++d) held[d] = rays_in(tails.data() + (size_t) (d - 1) * kCountsPerDepth);
+		for (unsigned d = max_depth; d >= 1; --d) {
+			if (held[d] <= chunk) continue;
+			PtxStatus rst = run(run, d, chunk, held[d]);
+			if (rst != PTX_OK) return rst;
+		}
 	}
 	HIP_TRY(hipGetLastError());
 	if (check_overflow || stats) {
