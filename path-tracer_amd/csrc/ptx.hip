@@ -53,7 +53,7 @@ constexpr unsigned kMaxBounces = 63;
 constexpr unsigned kNQ = 64;
 constexpr unsigned kCountPad = 32;  // words between two tail counters
 constexpr unsigned kCountsPerDepth = kNQ * kCountPad;
-constexpr size_t kCountBytes = (size_t) 2 * (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);  // ray-queue tails, then shadow-queue tails
+constexpr size_t kCountBytes = (size_t) 3 * (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);  // ray-queue tails, shadow-queue tails, hit-list tails
 
 // ---------------------------------------------------------------------------
 // device scene
@@ -131,6 +131,7 @@ struct DevCamera {  // Renderer::render's camera basis, framework/renderer.cpp:2
 	float aa_unit;  // 1.0f / aa_steps
 	float half_w, half_h;
 	uint32_t width, height, aa_steps;
+	double inv_width, inv_aa;  // 1.0 / width, 1.0 / aa_steps (udivmod)
 };
 
 struct RayQueue {  // SoA of float4: each store/load is 16 B per lane, 1 KiB per wave, contiguous
@@ -450,6 +451,25 @@ struct LightTerm {
 	float dist;
 	bool has_spec;
 };
+// (float) pow((double) x, (double) m) for a material exponent that is a whole number in
+// [1, kIntPowMax]: square-and-multiply in double.  Every product is rounded once, so the
+// result is within about m * 2^-54 of the true power, far inside what survives the final
+// rounding to float (the general pow of the device library is as accurate but keeps some
+// forty more registers live, which costs the shading kernels a wave per SIMD).  x >= 0, or
+// NaN, which the products pass on like pow does.
+constexpr float kIntPowMax = 4095.0f;
+__device__ __forceinline__ float pow_int(float x, float m) {
+	double b = (double) x, r = 1.0;
+	unsigned e = (unsigned) m;
+	while (__ballot(e != 0)) {
+		if (e & 1u) r *= b;
+		b *= b;
+		e >>= 1;
+	}
+	return (float) r;
+}
+
+template <bool INTPOW>
 __device__ __forceinline__ bool light_term(const DevScene& S, int l, const Surface& sf, f3 kd, f3 ks, float m, LightTerm& T) {
 	const float4 lp = kload(S.lights_k + 2 * l), li = kload(S.lights_k + 2 * l + 1);
 	f3 ldir = mk(lp.x, lp.y, lp.z) - sf.pos;
@@ -465,7 +485,7 @@ __device__ __forceinline__ bool light_term(const DevScene& S, int l, const Surfa
 		f3 r = 2 * dot(sf.n, ldir) * sf.n - ldir;
 		float cs = dot(r, sf.rdir * -1.0f);
 		if (!(cs < 0.0f)) {
-			float f = (float) pow((double) cs, (double) m);
+			float f = INTPOW ? pow_int(cs, m) : (float) pow((double) cs, (double) m);
 			T.spec = cmul(I, ks) * f;
 		}
 	}
@@ -474,11 +494,12 @@ __device__ __forceinline__ bool light_term(const DevScene& S, int l, const Surfa
 }
 
 // Renderer::phong_color with the shadow walk inline (fused pipeline)
+template <bool INTPOW>
 __device__ __forceinline__ f3 phong(const DevScene& S, const Surface& sf, const Material& M, int* __restrict__ stk, unsigned& n_shadow) {
 	f3 col = cmul(ld3(S.ambient), M.ka);
 	for (int l = 0; l < S.n_lights; ++l) {
 		LightTerm T;
-		if (!light_term(S, l, sf, M.kd, M.ks, M.m, T)) continue;
+		if (!light_term<INTPOW>(S, l, sf, M.kd, M.ks, M.m, T)) continue;
 		++n_shadow;
 		if (trace_any(S, sf.pos, T.ldir, T.dist, stk)) continue;
 		col = col + T.diffuse;
@@ -564,10 +585,11 @@ __device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& 
 }
 
 // Renderer::shade for the fused pipeline: weight * (phong * opacity * k1), children out
+template <bool INTPOW>
 __device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, f3 weight, bool last_depth, int* __restrict__ stk, Child& refl,
                                     Child& refr, unsigned& n_shadow) {
 	Material M = load_material(S, sf.material);
-	f3 c = phong(S, sf, M, stk, n_shadow) * M.opacity;
+	f3 c = phong<INTPOW>(S, sf, M, stk, n_shadow) * M.opacity;
 	float k1;
 	bounce_terms(sf, M, weight, last_depth, refl, refr, k1);
 	c = c * k1;
@@ -612,10 +634,25 @@ __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned p
 	}
 }
 
+// u / n and u % n for u < 2^31 with inv = 1.0 / n in double: the product is below the true
+// quotient by less than one, so truncating it gives the quotient or one less, which the
+// remainder shows.  (A handful of instructions; the compiler's 32-bit division takes about
+// 25 and the 64-bit one well over a hundred, per ray.)
+__device__ __forceinline__ void udivmod(unsigned u, unsigned n, double inv, unsigned& q, unsigned& r) {
+	q = (unsigned) ((double) u * inv);
+	r = u - q * n;
+	if (r >= n) {
+		++q;
+		r -= n;
+	}
+}
+
 __device__ __forceinline__ void make_primary(const DevCamera& cam, unsigned pixel, unsigned s, f3& o, f3& d) {
 	// framework/renderer.cpp:66-67, :76-82
-	unsigned x = pixel % cam.width, y = pixel / cam.width;
-	int aax = (int) (s / cam.aa_steps), aay = (int) (s % cam.aa_steps);
+	unsigned x, y, ax, ay;
+	udivmod(pixel, cam.width, cam.inv_width, y, x);
+	udivmod(s, cam.aa_steps, cam.inv_aa, ax, ay);
+	int aax = (int) ax, aay = (int) ay;
 	f3 pp = {x + aax * cam.aa_unit - cam.half_w, y + aay * cam.aa_unit - cam.half_h, -cam.dist};
 	f3 n = normalize(pp);
 	d = xform_dir(cam.m, n);
@@ -635,7 +672,8 @@ struct BounceArgs {
 	unsigned in_subcap;
 	unsigned in_offset;        // first ray (in the concatenation of the sub-queues) this launch takes
 	unsigned in_take;          // rays this launch takes from in_offset on; 0 = all of them
-	unsigned long long first;  // depth 0: first linear sample index of the batch
+	unsigned first_pix, first_s;  // depth 0: the batch starts at sample first_s (< ns) of this render's range in pixel first_pix
+	double inv_ns;             // 1.0 / ns
 	unsigned batch;            // depth 0: samples in the batch; depth > 0 with in_count == NULL: rays to take
 	unsigned ns, s0;           // samples per pixel in this render's range, first sample
 	unsigned depth;
@@ -647,17 +685,18 @@ struct BounceArgs {
 	RayQueue shadow;           // a = (o.xyz, d.x)  b = (d.yz, range, bits(pixel))  c = (contribution rgb, -)
 	unsigned* shadow_count;    // kNQ tail counters of `shadow`
 	unsigned shadow_subcap;
-	float4* hits;              // one record per input ray of the launch: (t, bits(id), bits(frame), bits(slot))
+	float4* hits;              // hit list of the launch, sub-queued like the ray queues: (t, bits(prim id), bits(where), bits(ray index))
+	unsigned* hit_count;       // kNQ tail counters of `hits`
+	unsigned hit_subcap;
 };
 
-// number of input rays of a launch; for depth > 0 also the first ray index of every
-// sub-queue of `in` (pfx, in LDS).  All threads of the workgroup must call it.
-template <bool PRIMARY>
-__device__ __forceinline__ unsigned launch_input(const BounceArgs& A, const unsigned* in_count, unsigned in_subcap, unsigned* pfx) {
-	if (PRIMARY) return A.batch;
+// Records held by a sub-queued queue: fills pfx (in LDS) with the first record index of every
+// sub-queue in their concatenation and returns how many of the records from `offset` on the
+// launch takes (`take` = 0: all of them).  All threads of the workgroup must call it.
+__device__ __forceinline__ unsigned queue_input(const unsigned* count, unsigned subcap, unsigned* pfx, unsigned offset, unsigned take) {
 	const unsigned lane = lane_id();
 	if (threadIdx.x < 64) {
-		unsigned c = min(in_count[threadIdx.x * kCountPad], in_subcap);
+		unsigned c = min(count[threadIdx.x * kCountPad], subcap);
 		for (int off = 1; off < 64; off <<= 1) {
 			unsigned t = __shfl_up(c, off);
 			if (lane >= (unsigned) off) c += t;
@@ -667,8 +706,14 @@ __device__ __forceinline__ unsigned launch_input(const BounceArgs& A, const unsi
 	}
 	__syncthreads();
 	const unsigned total_in = pfx[kNQ];
-	const unsigned avail = total_in > A.in_offset ? total_in - A.in_offset : 0;
-	return A.in_take ? min(A.in_take, avail) : avail;
+	const unsigned avail = total_in > offset ? total_in - offset : 0;
+	return take ? min(take, avail) : avail;
+}
+// number of input rays of a launch: the primary batch, or what the launch takes of queue `in`
+template <bool PRIMARY>
+__device__ __forceinline__ unsigned launch_input(const BounceArgs& A, unsigned* pfx) {
+	if (PRIMARY) return A.batch;
+	return queue_input(A.in_count, A.in_subcap, pfx, A.in_offset, A.in_take);
 }
 
 // ray index of the launch -> record index in a sub-queued queue (binary search over pfx)
@@ -688,9 +733,10 @@ __device__ __forceinline__ size_t queue_slot(const unsigned* pfx, unsigned subca
 template <bool PRIMARY>
 __device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* pfx, unsigned i, f3& o, f3& d, f3& w, unsigned& pix) {
 	if (PRIMARY) {
-		unsigned long long li = A.first + i;
-		pix = (unsigned) (li / A.ns);
-		unsigned s = A.s0 + (unsigned) (li - (unsigned long long) pix * A.ns);
+		unsigned dp, s;
+		udivmod(A.first_s + i, A.ns, A.inv_ns, dp, s);
+		pix = A.first_pix + dp;
+		s += A.s0;
 		make_primary(A.cam, pix, s, o, d);
 		w = mk(1, 1, 1);
 	} else {
@@ -703,19 +749,41 @@ __device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* p
 	}
 }
 
+// Sub-queue that takes the records a wave emits for the step starting at ray `base` of a
+// launch: the steps go round the sub-queues.
+__device__ __forceinline__ unsigned sub_queue_of(unsigned long long base, unsigned total) {
+	(void) total;
+	return (unsigned) (base >> 6) & (kNQ - 1);
+}
+
 // wave64 ballot compaction of up to two records per lane into sub-queue q of a queue: the
-// records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.
-__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned q, bool live1, const float4 r1[3],
-                                          bool live2, const float4 r2[3], Counters* counters) {
-	const unsigned lane = lane_id();
-	unsigned long long m1 = __ballot(live1), m2 = __ballot(live2);
-	unsigned total = __builtin_popcountll(m1) + __builtin_popcountll(m2);
+// records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.  The
+// two halves are separate calls so that a kernel can put independent work between asking
+// for the slots and needing them (the atomic's round trip to the memory side is long).
+struct Reserved {
+	unsigned slot0;  // lane 0 only until emit_write broadcasts it
+	unsigned q;
+	unsigned long long m1, m2;
+};
+__device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned long long base, bool live1, bool live2) {
+	Reserved R;
+	R.m1 = __ballot(live1);
+	R.m2 = __ballot(live2);
+	R.slot0 = 0;
+	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
+	R.q = sub_queue_of(base, total);
+	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + R.q * kCountPad, total);
+	return R;
+}
+__device__ __forceinline__ void emit_write(const RayQueue& Q, unsigned subcap, const Reserved& R, bool live1, const float4 r1[3],
+                                           bool live2, const float4 r2[3], Counters* counters) {
+	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
 	if (!total) return;
-	unsigned slot0 = 0;
-	if (lane == 0) slot0 = atomicAdd(tails + q * kCountPad, total);
-	slot0 = __shfl(slot0, 0);
+	const unsigned lane = lane_id();
+	const unsigned q = R.q;
+	const unsigned slot0 = __shfl(R.slot0, 0);
 	unsigned long long lt = lanes_below(lane);
-	unsigned my = slot0 + __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
+	unsigned my = slot0 + __builtin_popcountll(R.m1 & lt) + __builtin_popcountll(R.m2 & lt);
 	const size_t qbase = (size_t) q * subcap;
 	if (live1) {
 		if (my < subcap) {
@@ -731,6 +799,11 @@ __device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, un
 		Q.c[qbase + my] = r2[2];
 	}
 	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);
+}
+__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned long long base, bool live1,
+                                          const float4 r1[3], bool live2, const float4 r2[3], Counters* counters) {
+	const Reserved R = emit_reserve(tails, base, live1, live2);
+	emit_write(Q, subcap, R, live1, r1, live2, r2, counters);
 }
 
 __device__ __forceinline__ void pack_child(const Child& c, unsigned pix, float4 r[3]) {
@@ -761,13 +834,13 @@ __device__ __forceinline__ void wave_stats(const BounceArgs& A, unsigned wave, u
 }
 
 // ---- fused pipeline: one kernel per depth -----------------------------------------------
-template <bool PRIMARY>
+template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ unsigned pfx[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, A.in_count, A.in_subcap, pfx);
+	const unsigned n = launch_input<PRIMARY>(A, pfx);
 	const unsigned waves_per_block = kBlock / 64;
 	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * waves_per_block;
@@ -791,71 +864,88 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 		refl.live = refr.live = false;
 		if (hit) {
 			Surface sf = surface_of(A.S, o, d, h);
-			contrib = shade(A.S, sf, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
+			contrib = shade<INTPOW>(A.S, sf, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
 			++cnt_hits;
 		}
 		accumulate(A.accum, pix, contrib, hit);
 		float4 r1[3], r2[3];
 		pack_child(refl, pix, r1);
 		pack_child(refr, pix, r2);
-		emit_pair(A.out, A.out_count, A.out_subcap, (unsigned) (base >> 6) & (kNQ - 1), refl.live, r1, refr.live, r2, A.counters);
+		emit_pair(A.out, A.out_count, A.out_subcap, base, refl.live, r1, refr.live, r2, A.counters);
 	}
 	wave_stats(A, wave, cnt_trace, cnt_shadow, cnt_hits);
 }
 
 // ---- staged pipeline: closest hit / shading / shadow rays as three lean kernels ---------
-// (k_trace needs no shading state and k_shade no traversal state, so each fits twice the
-//  waves per SIMD of the fused kernel; the price is the hit record and the shadow rays
-//  going through HBM)
+// k_trace needs no shading state and k_shade no traversal state, so each fits twice the
+// waves per SIMD of the fused kernel.  k_trace leaves a compacted list of 16-byte hit
+// records (most primary rays of a typical frame hit nothing), so k_shade runs full waves of
+// hits only and fetches (or, at depth 0, regenerates) just the rays that hit.
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ unsigned pfx[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, A.in_count, A.in_subcap, pfx);
+	const unsigned n = launch_input<PRIMARY>(A, pfx);
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	unsigned cnt_trace = 0;
+	// The slots of a step's hit records come from a returning atomic, whose round trip to the
+	// memory side is about as long as a short traversal.  The records of step k are therefore
+	// kept in registers and written during step k + 1, when the answer has long arrived.
+	bool pend = false, p_hit = false;
+	float4 p_rec = make_float4(0, 0, 0, 0);
+	unsigned p_slot0 = 0, p_rank = 0, p_total = 0, p_q = 0;
+	auto flush = [&]() {
+		const unsigned slot0 = __shfl(p_slot0, 0);
+		const unsigned my = slot0 + p_rank;
+		if (p_hit && my < A.hit_subcap) A.hits[(size_t) p_q * A.hit_subcap + my] = p_rec;
+		if (lane == 0 && slot0 + p_total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);
+	};
 	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
 		unsigned i = (unsigned) base + lane;
-		if (i >= n) continue;
-		f3 o, d, w;
-		unsigned pix;
-		input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
 		Hit h;
-		trace_closest(A.S, o, d, stk, h);
-		++cnt_trace;
-		A.hits[i] = make_float4(h.t, __int_as_float(h.id), __int_as_float(h.frame), __int_as_float(h.slot));
+		h.id = -1;
+		if (i < n) {
+			f3 o, d, w;
+			unsigned pix;
+			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+			trace_closest(A.S, o, d, stk, h);
+			++cnt_trace;
+		}
+		if (pend) flush();
+		const bool hit = h.id >= 0;
+		const unsigned long long m = __ballot(hit);
+		pend = m != 0;
+		if (!pend) continue;
+		p_total = __builtin_popcountll(m);
+		p_q = sub_queue_of(base, p_total);
+		if (lane == 0) p_slot0 = atomicAdd(A.hit_count + p_q * kCountPad, p_total);
+		p_rank = __builtin_popcountll(m & lanes_below(lane));
+		p_hit = hit;
+		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
+		const int where = h.frame == 0 ? h.slot : -h.frame;
+		p_rec = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(i));
 	}
+	if (pend) flush();
 	wave_stats(A, wave, cnt_trace, 0, 0);
 }
 
-template <bool PRIMARY>
+template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
+	__shared__ unsigned pfx_hit[kNQ + 1];
 	__shared__ unsigned pfx[kNQ + 1];
-	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, A.in_count, A.in_subcap, pfx);
+	const unsigned n = queue_input(A.hit_count, A.hit_subcap, pfx_hit, 0, 0);
+	if (!PRIMARY) (void) launch_input<false>(A, pfx);
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	unsigned cnt_shadow = 0, cnt_hits = 0;
 	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
-		bool active = i < n;
-		Hit h;
-		h.id = -1;
-		if (active) {
-			float4 hr = A.hits[i];
-			h.t = hr.x;
-			h.id = __float_as_int(hr.y);
-			h.frame = __float_as_int(hr.z);
-			h.slot = __float_as_int(hr.w);
-		}
-		const bool hit = active && h.id >= 0;
-		if (__ballot(hit) == 0) continue;  // the whole step missed: nothing to shade, nothing to emit
+		const unsigned i = (unsigned) base + lane_id();
+		const bool hit = i < n;
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
-		if (active) input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
 		Surface sf;
 		sf.pos = sf.n = sf.rdir = mk(0, 0, 0);
 		f3 kd = {0, 0, 0}, ks = {0, 0, 0}, ws = {0, 0, 0};
@@ -864,6 +954,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 		Child refl, refr;
 		refl.live = refr.live = false;
 		if (hit) {
+			const float4 hr = A.hits[queue_slot(pfx_hit, A.hit_subcap, i)];
+			Hit h;
+			h.t = hr.x;
+			h.id = __float_as_int(hr.y);
+			const int where = __float_as_int(hr.z);
+			h.frame = where < 0 ? -where : 0;
+			h.slot = where < 0 ? 0 : where;
+			input_ray<PRIMARY>(A, pfx, __float_as_uint(hr.w), o, d, w, pix);
 			sf = surface_of(A.S, o, d, h);
 			Material M = load_material(A.S, sf.material);
 			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
@@ -876,8 +974,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 			contrib = cmul(w, (cmul(ld3(A.S.ambient), M.ka) * M.opacity) * k1);
 			++cnt_hits;
 		}
-		accumulate(A.accum, pix, contrib, hit);
-		const unsigned q = (unsigned) (base >> 6) & (kNQ - 1);
+		// the slots of the child rays are asked for first and used last: the light terms, the
+		// shadow records and the accumulation all fit inside that atomic's round trip
+		const Reserved rc = emit_reserve(A.out_count, base, refl.live, refr.live);
+		bool accumulated = false;
 		// one shadow ray per light whose term can add something; its record carries the finished
 		// contribution weight * ((diffuse + specular) * opacity * k1)
 		for (int l = 0; l < A.S.n_lights; ++l) {
@@ -885,7 +985,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 			float4 r[3];
 			if (hit) {
 				LightTerm T;
-				want = light_term(A.S, l, sf, kd, ks, mm, T);
+				want = light_term<INTPOW>(A.S, l, sf, kd, ks, mm, T);
 				f3 term = T.diffuse;
 				if (T.has_spec) term = term + T.spec;
 				f3 c = cmul(ws, (term * scale0) * k1);
@@ -894,12 +994,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 				r[2] = make_float4(c.x, c.y, c.z, 0.f);
 			}
 			if (want) ++cnt_shadow;
-			emit_pair(A.shadow, A.shadow_count, A.shadow_subcap, q, want, r, false, r, A.counters);
+			const Reserved rs = emit_reserve(A.shadow_count, base, want, false);
+			if (!accumulated) accumulate(A.accum, pix, contrib, hit);
+			accumulated = true;
+			emit_write(A.shadow, A.shadow_subcap, rs, want, r, false, r, A.counters);
 		}
+		if (!accumulated) accumulate(A.accum, pix, contrib, hit);
 		float4 r1[3], r2[3];
 		pack_child(refl, pix, r1);
 		pack_child(refr, pix, r2);
-		emit_pair(A.out, A.out_count, A.out_subcap, q, refl.live, r1, refr.live, r2, A.counters);
+		emit_write(A.out, A.out_subcap, rc, refl.live, r1, refr.live, r2, A.counters);
 	}
 	wave_stats(A, wave, 0, cnt_shadow, cnt_hits);
 }
@@ -911,10 +1015,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(BounceArgs A) {
 	__shared__ unsigned pfx[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	BounceArgs B = A;
-	B.in_offset = 0;
-	B.in_take = 0;
-	const unsigned n = launch_input<false>(B, A.shadow_count, A.shadow_subcap, pfx);
+	const unsigned n = queue_input(A.shadow_count, A.shadow_subcap, pfx, 0, 0);
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
@@ -1089,6 +1190,7 @@ struct PtxScene {
 	unsigned long long* d_stat = nullptr;
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
+	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
 	bool profiling = false;
 	std::vector<hipEvent_t> events;      // pairs, reused from call to call
 	std::vector<unsigned> event_tag;     // kernel kind and depth of pair k
@@ -1129,13 +1231,15 @@ void camera_basis(const PtxCamera& c, const PtxRenderParams& rp, DevCamera& out)
 	out.width = rp.width;
 	out.height = rp.height;
 	out.aa_steps = rp.aa_steps;
+	out.inv_width = 1.0 / rp.width;
+	out.inv_aa = 1.0 / rp.aa_steps;
 }
 
 PtxStatus check_params(const PtxRenderParams* p) {
 	if (!p) return fail(PTX_ERR_INVALID, "params is NULL");
 	if (p->width == 0 || p->height == 0 || p->aa_steps == 0) return fail(PTX_ERR_INVALID, "width, height and aa_steps must be positive");
 	if ((uint64_t) p->width * p->height > 0x7fffffffull / 3) return fail(PTX_ERR_INVALID, "image too large");
-	if ((uint64_t) p->aa_steps * p->aa_steps > 0xffffffffull) return fail(PTX_ERR_INVALID, "aa_steps too large");
+	if (p->aa_steps > 32768u) return fail(PTX_ERR_INVALID, "aa_steps too large (at most 32768)");
 	if (p->sample_begin > p->sample_end || p->sample_end > p->aa_steps * p->aa_steps)
 		return fail(PTX_ERR_INVALID, "sample range outside [0, aa_steps^2]");
 	if (p->max_ray_bounces > kMaxBounces) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must not exceed 63");
@@ -1195,6 +1299,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		bool refl = m.glossy > 0, refr = m.opacity < 1;
 		if (refl && refr) sc->branching = true;
 		if (refl || refr) sc->bouncing = true;
+		if (m.m != 0.0f && !(m.m >= 1.0f && m.m <= kIntPowMax && m.m == std::floor(m.m))) sc->int_pow = false;
 	}
 	std::vector<float4> lights((size_t) D->n_lights * 2);
 	for (int i = 0; i < D->n_lights; ++i) {
@@ -1423,6 +1528,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	A.stat = sc->d_stat;
 	const unsigned ns = rp->sample_end - rp->sample_begin;
 	A.ns = ns;
+	A.inv_ns = 1.0 / ns;
 	A.s0 = rp->sample_begin;
 	const uint64_t total = (uint64_t) rp->width * rp->height * ns;
 	const unsigned max_depth = sc->bouncing ? rp->max_ray_bounces : 0;  // no material spawns rays: depth 0 only
@@ -1456,24 +1562,27 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	};
 	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountsPerDepth; };
 	auto shadow_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (kMaxBounces + 2 + depth) * kCountsPerDepth; };
+	auto hit_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kCountsPerDepth; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
+	const bool ip = sc->int_pow;
 	auto launch_depth = [&](unsigned d, unsigned grid) -> PtxStatus {
 		if (!staged) {
 			HIP_TRY(tick(0, d, true));
-			if (d == 0) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), 0, stream, A);
-			else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+			auto kern = d == 0 ? (ip ? k_bounce<true, true> : k_bounce<true, false>) : (ip ? k_bounce<false, true> : k_bounce<false, false>);
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(0, d, false));
 			launches += 1;
 			return PTX_OK;
 		}
 		A.shadow_count = shadow_count_of(d);
+		A.hit_count = hit_count_of(d);
 		HIP_TRY(tick(0, d, true));
 		if (d == 0) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, stream, A);
 		else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, stream, A);
 		HIP_TRY(tick(0, d, false));
 		HIP_TRY(tick(1, d, true));
-		if (d == 0) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kBlock), 0, stream, A);
-		else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+		auto kern = d == 0 ? (ip ? k_shade<true, true> : k_shade<true, false>) : (ip ? k_shade<false, true> : k_shade<false, false>);
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, A);
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
@@ -1504,8 +1613,9 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	};
 	auto place_staged = [&](unsigned queues, uint64_t cap) {  // shadow queue and hit records behind the ray queues
 		A.shadow = queue_at((uint64_t) queues * cap, cap);
-		A.shadow_subcap = (unsigned) (cap / kNQ);
+		A.shadow_subcap = (unsigned) std::min<uint64_t>(cap / kNQ, 1u << 25);
 		A.hits = sc->qmem + ((uint64_t) queues + 1) * cap * 3;
+		A.hit_subcap = (unsigned) std::min<uint64_t>(cap / kNQ, 1u << 25);
 	};
 
 	// Driving the ray tree through the queues: queue d (1..max_depth) holds the rays traced at
@@ -1551,6 +1661,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 			const bool last = (d == max_depth);
 			if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
+			if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			set_depth(d, (unsigned) off, cnt);
 			PtxStatus ls = launch_depth(d, (unsigned) sc->grid);
 			if (ls != PTX_OK) return ls;
@@ -1569,7 +1680,9 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		const unsigned cnt = (unsigned) std::min<uint64_t>(chunk, total - first);
 		if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
 		if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
-		A.first = first;
+		if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
+		A.first_pix = (unsigned) (first / ns);
+		A.first_s = (unsigned) (first % ns);
 		A.batch = cnt;
 		for (unsigned d = 0; d <= max_depth; ++d) {
 			set_depth(d, 0, chunk);
