@@ -112,7 +112,8 @@ struct DevScene {
 	const float4* nodes;      // 4 float4 per node
 	const float4* tris;       // 3 float4 per triangle: (v0, e1.x) (e1.yz, e2.xy) (e2.z, id, -, -)
 	const float4* prim_info;  // per prim id: (n.x, n.y, n.z, bits(material | levels_in << 16))
-	const float4* materials;  // 4 float4 per material: (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
+	const float4* materials;  // 4 float4 per PRIM id (its material, so that a hit needs no second, dependent fetch):
+	                          // (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
 	const float4* lights;     // 2 float4 per light: (pos, -) (intensity, -)
 	// the same tables once more, for the wave-uniform reads (kload)
 	PTX_KPTR(DevRootPrim) root_prims_k;
@@ -260,6 +261,10 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 				const float4* tr = tris + (size_t) (first + k) * 3;
 				float4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
 				float t;
+#if !defined(PTX_NO_TRI_EARLY)
+				// most tests end at the first barycentric coordinate: when they do so for the whole wave, skip the rest
+				if (!__ballot(tri_u_ok(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d))) continue;
+#endif
 				if (tri_t(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, t)) {
 					if (ANY) {
 						if (t <= range) return true;
@@ -415,7 +420,6 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 
 struct Surface {  // the HitPoint fields shading reads, framework/hitPoint.hpp:8-16
 	f3 pos, n, rdir;
-	int material;
 };
 
 // Rebuilds position / normal / ray_direction of the winning leaf exactly as the leaf and
@@ -429,7 +433,7 @@ __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, con
 		const int kind = P.kind_flags & 0xff;
 		// the shape's real matrices, also for translated-only shapes: the zeros of an inverted
 		// translation carry signs, and the sign of a zero normal component follows them
-		const DevXform& X = S.xforms[P.xform];
+		const DevXform& X = S.xforms[h.slot];  // one per root leaf, in the same order
 		f3 lo = xform_point(X.winv, o), ld = xform_dir(X.winv, d);
 		if (kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
 			s.pos = xform_point(X.w, lo + ld * h.t);
@@ -445,7 +449,6 @@ __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, con
 			s.rdir = ld;
 			s.n = xform_dir(X.w, ld3(Q.n));
 		}
-		s.material = Q.material;
 		levels = Q.levels_in;
 	} else {
 		const DevFrame& F = S.frames[h.frame];  // h.frame differs between lanes: ordinary loads
@@ -454,7 +457,6 @@ __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, con
 		f3 lo = xform_point(Fwinv, o), ld = xform_dir(Fwinv, d);
 		float4 info = S.prim_info[h.id];
 		int packed = __float_as_int(info.w);
-		s.material = packed & 0xffff;
 		int lin = (packed >> 16) & 0xff;
 		f3 n = {info.x, info.y, info.z};
 		for (int k = 0; k < lin; ++k) n = normalize(n);  // octants / sub-objects, identity transform
@@ -471,8 +473,8 @@ struct Material {
 	f3 ka, kd, ks;
 	float m, glossy, opacity, ior;
 };
-__device__ __forceinline__ Material load_material(const DevScene& S, int i) {
-	const float4* p = S.materials + (size_t) i * 4;
+__device__ __forceinline__ Material load_material(const DevScene& S, int prim_id) {
+	const float4* p = S.materials + (size_t) prim_id * 4;
 	float4 a = p[0], b = p[1], c = p[2], e = p[3];
 	return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, c.y, c.z, c.w, e.x};
 }
@@ -621,9 +623,9 @@ __device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& 
 
 // Renderer::shade for the fused pipeline: weight * (phong * opacity * k1), children out
 template <bool INTPOW>
-__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, f3 weight, bool last_depth, int* __restrict__ stk, Child& refl,
-                                    Child& refr, unsigned& n_shadow) {
-	Material M = load_material(S, sf.material);
+__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, int prim_id, f3 weight, bool last_depth, int* __restrict__ stk,
+                                    Child& refl, Child& refr, unsigned& n_shadow) {
+	Material M = load_material(S, prim_id);
 	f3 c = phong<INTPOW>(S, sf, M, stk, n_shadow) * M.opacity;
 	float k1;
 	bounce_terms(sf, M, weight, last_depth, refl, refr, k1);
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 		refl.live = refr.live = false;
 		if (hit) {
 			Surface sf = surface_of(A.S, o, d, h);
-			contrib = shade<INTPOW>(A.S, sf, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
+			contrib = shade<INTPOW>(A.S, sf, h.id, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
 			++cnt_hits;
 		}
 		accumulate(A.accum, pix, contrib, hit);
@@ -976,9 +978,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	unsigned cnt_shadow = 0, cnt_hits = 0;
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
+	// the hit record of a step is fetched one step ahead, so that its trip from memory runs
+	// beside the previous step's work instead of in front of this step's
+	const unsigned long long stride = (unsigned long long) n_waves * 64;
+	auto fetch_hit = [&](unsigned long long b) {
+		const unsigned j = (unsigned) b + lane_id();
+		return j < n ? A.hits[queue_slot(pfx_hit, A.hit_subcap, j)] : make_float4(0.f, 0.f, 0.f, 0.f);
+	};
+	unsigned long long base = (unsigned long long) wave * 64;
+	float4 hr_next = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (base < n) hr_next = fetch_hit(base);
+	for (; base < n; base += stride) {
 		const unsigned i = (unsigned) base + lane_id();
 		const bool hit = i < n;
+		const float4 hr = hr_next;
+		if (base + stride < n) hr_next = fetch_hit(base + stride);
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
 		Surface sf;
@@ -989,7 +1003,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 		Child refl, refr;
 		refl.live = refr.live = false;
 		if (hit) {
-			const float4 hr = A.hits[queue_slot(pfx_hit, A.hit_subcap, i)];
 			Hit h;
 			h.t = hr.x;
 			h.id = __float_as_int(hr.y);
@@ -998,7 +1011,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 			h.slot = where < 0 ? 0 : where;
 			input_ray<PRIMARY>(A, pfx, __float_as_uint(hr.w), o, d, w, pix);
 			sf = surface_of(A.S, o, d, h);
-			Material M = load_material(A.S, sf.material);
+			Material M = load_material(A.S, h.id);
 			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
 			kd = M.kd;
 			ks = M.ks;
@@ -1516,7 +1529,11 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	}
 	if ((st = sc->upload(tris, &S.tris)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(prim_info, &S.prim_info)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
-	if ((st = sc->upload(mats, &S.materials)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	{
+		std::vector<float4> prim_mats((size_t) std::max(D->n_prims, 1) * 4);
+		for (int i = 0; i < D->n_prims; ++i) std::memcpy(&prim_mats[(size_t) i * 4], &mats[(size_t) D->prims[i].material * 4], 4 * sizeof(float4));
+		if ((st = sc->upload(prim_mats, &S.materials)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	}
 	if ((st = sc->upload(lights, &S.lights)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	// same addresses; copied as bits because the device pass types the *_k members differently
 	std::memcpy(&S.root_prims_k, &S.root_prims, sizeof(void*));
@@ -1617,7 +1634,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	HIP_TRY(hipMemsetAsync(sc->d_stat, 0, kStatBytes, stream));
 	uint64_t launches = 0;
 	const bool prof = sc->profiling && stats;
-	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED;  // the default is the fused pipeline (the faster one on the measured scenes)
+	const bool staged = rp->pipeline != PTX_PIPELINE_FUSED;  // the default is the staged pipeline (the faster one on the measured scenes)
 	sc->event_tag.clear();
 	// profiling: a pair of events around every launch; tag = kind * kMaxDepthSlots + depth slot
 	auto tick = [&](unsigned kind, unsigned depth, bool begin) -> hipError_t {

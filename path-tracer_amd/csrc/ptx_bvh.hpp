@@ -32,7 +32,10 @@ struct Bvh {
 	bool empty = true;
 };
 
-constexpr int kBvhMaxLeaf = 4;
+#ifndef PTX_BVH_MAX_LEAF
+#define PTX_BVH_MAX_LEAF 4
+#endif
+constexpr int kBvhMaxLeaf = PTX_BVH_MAX_LEAF;
 constexpr int kBvhMaxDepth = 30;
 
 // boxes must be finite.  Deterministic (no threading, no RNG).

@@ -136,6 +136,18 @@ __device__ __forceinline__ bool tri_t(f3 v0, f3 e1, f3 e2, f3 o, f3 d, float& t)
 	return !(parallel || bad_u || bad_v || bad_t);
 }
 
+// first two rejections of tri_t (same operations, so the compiler shares them with tri_t):
+// false when the ray is parallel to the triangle or u is outside [0, 1]
+__device__ __forceinline__ bool tri_u_ok(f3 v0, f3 e1, f3 e2, f3 o, f3 d) {
+	f3 p = cross(d, e2);
+	float det = dot(e1, p);
+	const bool parallel = det < kEps && det > -kEps;
+	float inv_det = 1.0f / det;
+	f3 tv = o - v0;
+	float u = dot(tv, p) * inv_det;
+	return !(parallel || u < 0.0f || u > 1.0f);
+}
+
 // Renderer::schlick_reflection_ratio, framework/renderer.cpp:252-276
 __device__ __forceinline__ float schlick(f3 rd, f3 n, float ior) {
 	float n1 = 1.0f, n2 = ior;
