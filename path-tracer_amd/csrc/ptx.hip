@@ -137,10 +137,10 @@ struct DevCamera {  // Renderer::render's camera basis, framework/renderer.cpp:2
 	double inv_width, inv_aa;  // 1.0 / width, 1.0 / aa_steps (udivmod)
 };
 
-struct RayQueue {  // SoA of float4: each store/load is 16 B per lane, 1 KiB per wave, contiguous
+struct RayQueue {  // SoA planes: each store/load is 16 (8) B per lane, contiguous across the wave; 40 B per ray
 	float4* a;     // (o.x, o.y, o.z, d.x)
 	float4* b;     // (d.y, d.z, w.r, w.g)
-	float4* c;     // (w.b, bits(pixel), -, -)
+	float2* c;     // (w.b, bits(pixel))
 };
 
 struct Hit {
@@ -426,7 +426,6 @@ struct Surface {  // the HitPoint fields shading reads, framework/hitPoint.hpp:8
 // the Composites above it would have produced them.
 __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
 	Surface s;
-	int levels;
 	if (h.frame == 0) {
 		const DevRootPrim& P = S.root_prims[h.slot];
 		const DevRootShade& Q = S.root_shade[h.slot];
@@ -435,37 +434,31 @@ __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, con
 		// translation carry signs, and the sign of a zero normal component follows them
 		const DevXform& X = S.xforms[h.slot];  // one per root leaf, in the same order
 		f3 lo = xform_point(X.winv, o), ld = xform_dir(X.winv, d);
-		if (kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
-			s.pos = xform_point(X.w, lo + ld * h.t);
-			s.n = normalize(s.pos - xform_point(X.w, ld3(P.p)));
-			s.rdir = d;
-		} else if (kind == PTX_BOX) {  // framework/box.cpp:98-100
-			f3 nl = box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t);
-			s.n = normalize(xform_dir(X.w, nl));
-			s.pos = o + d * h.t;
-			s.rdir = d;
-		} else {  // framework/triangle.cpp:86
+		if (kind == PTX_TRIANGLE) {  // framework/triangle.cpp:86
 			s.pos = o + d * h.t;
 			s.rdir = ld;
-			s.n = xform_dir(X.w, ld3(Q.n));
+			s.n = ld3(Q.n);  // constant per triangle: transformed and re-normalised at upload
+		} else {
+			if (kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
+				s.pos = xform_point(X.w, lo + ld * h.t);
+				s.n = normalize(s.pos - xform_point(X.w, ld3(P.p)));
+			} else {  // framework/box.cpp:98-100
+				f3 nl = box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t);
+				s.n = normalize(xform_dir(X.w, nl));
+				s.pos = o + d * h.t;
+			}
+			s.rdir = d;
+			for (int k = 0; k < Q.levels_in; ++k) s.n = normalize(s.n);  // identity-transform Composites up to the root
 		}
-		levels = Q.levels_in;
 	} else {
-		const DevFrame& F = S.frames[h.frame];  // h.frame differs between lanes: ordinary loads
-		const float* Fwinv = S.frame_winv[h.frame].m;
+		const float* Fwinv = S.frame_winv[h.frame].m;  // h.frame differs between lanes: ordinary loads
 		const float* Fw = S.frame_w[h.frame].m;
 		f3 lo = xform_point(Fwinv, o), ld = xform_dir(Fwinv, d);
 		float4 info = S.prim_info[h.id];
-		int packed = __float_as_int(info.w);
-		int lin = (packed >> 16) & 0xff;
-		f3 n = {info.x, info.y, info.z};
-		for (int k = 0; k < lin; ++k) n = normalize(n);  // octants / sub-objects, identity transform
-		s.n = normalize(xform_dir(Fw, n));  // the mesh Composite itself, composite.cpp:99-100
+		s.n = mk(info.x, info.y, info.z);  // constant per triangle: the whole chain of Composites applied at upload
 		s.pos = xform_point(Fw, lo + ld * h.t);
 		s.rdir = ld;  // stays in mesh-local space: Composite never maps ray_direction back
-		levels = F.levels_up;
 	}
-	for (int k = 0; k < levels; ++k) s.n = normalize(s.n);  // identity-transform Composites up to the root
 	return s;
 }
 
@@ -719,7 +712,7 @@ struct BounceArgs {
 	Counters* counters;        // overflow flag only
 	unsigned long long* stat;  // per-wave work counters
 	// staged pipeline only
-	RayQueue shadow;           // a = (o.xyz, d.x)  b = (d.yz, range, bits(pixel))  c = (contribution rgb, -)
+	RayQueue shadow;           // a = (o.xyz, bits(pixel))  b = (contribution rgb, bits(light)); plane c unused (32 B per shadow ray)
 	unsigned* shadow_count;    // kNQ tail counters of `shadow`
 	unsigned shadow_subcap;
 	float4* hits;              // hit list of the launch, sub-queued like the ray queues: (t, bits(prim id), bits(where), bits(ray index))
@@ -778,7 +771,8 @@ __device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* p
 		w = mk(1, 1, 1);
 	} else {
 		const size_t j = queue_slot(pfx, A.in_subcap, A.in_offset + i);
-		float4 a = A.in.a[j], b = A.in.b[j], c = A.in.c[j];
+		const float4 a = A.in.a[j], b = A.in.b[j];
+		const float2 c = A.in.c[j];
 		o = mk(a.x, a.y, a.z);
 		d = mk(a.w, b.x, b.y);
 		w = mk(b.z, b.w, c.x);
@@ -812,6 +806,7 @@ __device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned long 
 	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + R.q * kCountPad, total);
 	return R;
 }
+template <bool WITH_C = true>
 __device__ __forceinline__ void emit_write(const RayQueue& Q, unsigned subcap, const Reserved& R, bool live1, const float4 r1[3],
                                            bool live2, const float4 r2[3], Counters* counters) {
 	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
@@ -826,14 +821,14 @@ __device__ __forceinline__ void emit_write(const RayQueue& Q, unsigned subcap, c
 		if (my < subcap) {
 			Q.a[qbase + my] = r1[0];
 			Q.b[qbase + my] = r1[1];
-			Q.c[qbase + my] = r1[2];
+			if (WITH_C) Q.c[qbase + my] = make_float2(r1[2].x, r1[2].y);
 		}
 		++my;
 	}
 	if (live2 && my < subcap) {
 		Q.a[qbase + my] = r2[0];
 		Q.b[qbase + my] = r2[1];
-		Q.c[qbase + my] = r2[2];
+		if (WITH_C) Q.c[qbase + my] = make_float2(r2[2].x, r2[2].y);
 	}
 	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);
 }
@@ -970,7 +965,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 }
 
 template <bool PRIMARY, bool INTPOW>
-__global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) {
 	__shared__ unsigned pfx_hit[kNQ + 1];
 	__shared__ unsigned pfx[kNQ + 1];
 	const unsigned n = queue_input(A.hit_count, A.hit_subcap, pfx_hit, 0, 0);
@@ -1037,15 +1032,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(BounceArgs A) {
 				f3 term = T.diffuse;
 				if (T.has_spec) term = term + T.spec;
 				f3 c = cmul(ws, (term * scale0) * k1);
-				r[0] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, T.ldir.x);
-				r[1] = make_float4(T.ldir.y, T.ldir.z, T.dist, __uint_as_float(pix));
-				r[2] = make_float4(c.x, c.y, c.z, 0.f);
+				// (k_shadow forms the direction and distance to the light again, with the same operations)
+				r[0] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(pix));
+				r[1] = make_float4(c.x, c.y, c.z, __int_as_float(l));
+				r[2] = r[1];
 			}
 			if (want) ++cnt_shadow;
 			const Reserved rs = emit_reserve(A.shadow_count, base, want, false);
 			if (!accumulated) accumulate(A.accum, pix, contrib, hit);
 			accumulated = true;
-			emit_write(A.shadow, A.shadow_subcap, rs, want, r, false, r, A.counters);
+			emit_write<false>(A.shadow, A.shadow_subcap, rs, want, r, false, r, A.counters);
 		}
 		if (!accumulated) accumulate(A.accum, pix, contrib, hit);
 		float4 r1[3], r2[3];
@@ -1074,10 +1070,16 @@ __global__ __launch_bounds__(kBlock) void k_shadow(BounceArgs A) {
 		bool lit = false;
 		if (active) {
 			const size_t j = queue_slot(pfx, A.shadow_subcap, i);
-			float4 a = A.shadow.a[j], b = A.shadow.b[j], cc = A.shadow.c[j];
-			pix = __float_as_uint(b.w);
-			c = mk(cc.x, cc.y, cc.z);
-			lit = !trace_any(A.S, mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), b.z, stk);
+			const float4 a = A.shadow.a[j], b = A.shadow.b[j];
+			pix = __float_as_uint(a.w);
+			c = mk(b.x, b.y, b.z);
+			// direction and distance to the light exactly as light_term formed them (renderer.cpp:144-147)
+			const float4 lp = A.S.lights[2 * __float_as_int(b.w)];
+			const f3 pos = mk(a.x, a.y, a.z);
+			f3 ldir = mk(lp.x, lp.y, lp.z) - pos;
+			const float dist = length(ldir);
+			ldir = normalize(ldir);
+			lit = !trace_any(A.S, pos, ldir, dist, stk);
 		}
 		accumulate(A.accum, pix, c, lit);
 	}
@@ -1418,7 +1420,26 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		int packed = P.material | (P.levels_in << 16);
 		float pw;
 		std::memcpy(&pw, &packed, 4);
-		prim_info[i] = make_float4(P.normal[0], P.normal[1], P.normal[2], pw);
+		{
+			// The normal a hit on a triangle reports does not depend on the ray, so the chain the
+			// reference applies per hit is applied once here, with the device's own functions:
+			// mesh triangle - re-normalised by every Composite between it and the mesh
+			// (octants, sub-objects; identity transforms), mapped by the mesh's transform and
+			// normalised (composite.cpp:99-100), re-normalised by every Composite above the mesh;
+			// root triangle - mapped by its own transform (triangle.cpp:86), then re-normalised
+			// by the Composites above it.
+			f3 n = mk(P.normal[0], P.normal[1], P.normal[2]);
+			if (P.frame > 0) {
+				const PtxFrame& F = D->frames[P.frame];
+				for (int k = 0; k < P.levels_in; ++k) n = normalize(n);
+				n = normalize(xform_dir(F.world, n));
+				for (int k = 0; k < F.levels_up; ++k) n = normalize(n);
+			} else if (P.kind == PTX_TRIANGLE) {
+				n = xform_dir(P.world, n);
+				for (int k = 0; k < P.levels_in; ++k) n = normalize(n);
+			}
+			prim_info[i] = make_float4(n.x, n.y, n.z, pw);
+		}
 		bool finite = finite16(P.world) && finite16(P.world_inv);
 		for (int k = 0; k < 9; ++k) finite = finite && std::isfinite(P.p[k]);
 		if (P.frame == 0) {
@@ -1447,7 +1468,9 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 				xforms.push_back(X);
 			}
 			if (plain && P.kind == PTX_SPHERE) sc->dev.has_plain_sphere = 1;
-			std::memcpy(Q.n, P.normal, sizeof Q.n);
+			Q.n[0] = prim_info[i].x;
+			Q.n[1] = prim_info[i].y;
+			Q.n[2] = prim_info[i].z;
 			Q.levels_in = P.levels_in;
 			Q.material = P.material;
 			root_prims.push_back(R);
@@ -1654,7 +1677,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		RayQueue q;
 		q.a = sc->qmem + first_slot * 3;
 		q.b = q.a + cap;
-		q.c = q.b + cap;
+		q.c = reinterpret_cast<float2*>(q.b + cap);
 		return q;
 	};
 	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountsPerDepth; };

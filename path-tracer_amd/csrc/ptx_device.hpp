@@ -14,24 +14,26 @@ namespace ptxd {
 constexpr float kEps = 0.001f;  // EPSILON of framework/{renderer,sphere,box,triangle}.cpp
 constexpr float kInf = __builtin_huge_valf();
 
+// (the plain vector helpers are also callable on the host: the scene upload precomputes the
+// normals that do not depend on the ray with these very functions, same operations, same order)
 struct f3 {
 	float x, y, z;
 };
-__device__ __forceinline__ f3 mk(float x, float y, float z) { return {x, y, z}; }
-__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ f3 cmul(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }  // Color * Color
+__host__ __device__ __forceinline__ f3 mk(float x, float y, float z) { return {x, y, z}; }
+__host__ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__host__ __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__host__ __device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__host__ __device__ __forceinline__ f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__host__ __device__ __forceinline__ f3 cmul(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }  // Color * Color
 // glm detail/func_geometric.inl:61-68, :212-224, :104-110, :252-261
-__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
-__device__ __forceinline__ float length(f3 v) { return __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
-__device__ __forceinline__ f3 normalize(f3 v) {
+__host__ __device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__host__ __device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+__host__ __device__ __forceinline__ float length(f3 v) { return __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+__host__ __device__ __forceinline__ f3 normalize(f3 v) {
 	float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
 	return v * (1.0f / __builtin_sqrtf(sqr));
 }
-__device__ __forceinline__ bool any_nonzero(f3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
+__host__ __device__ __forceinline__ bool any_nonzero(f3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
 
 // std::min / std::max semantics (b < a ? b : a  /  a < b ? b : a), framework/box.cpp:123-147
 __device__ __forceinline__ float smin(float a, float b) { return b < a ? b : a; }
@@ -39,11 +41,11 @@ __device__ __forceinline__ float smax(float a, float b) { return a < b ? b : a; 
 
 // glm mat4 * vec4: (m0*x + m1*y) + (m2*z + m3*w), detail/type_mat4x4.inl:676-687.
 // M is column-major (element [c*4+r]).  transform_vec of framework/shape.cpp:46-48.
-__device__ __forceinline__ f3 xform_point(const float* __restrict__ M, f3 v) {
+__host__ __device__ __forceinline__ f3 xform_point(const float* __restrict__ M, f3 v) {
 	return {(M[0] * v.x + M[4] * v.y) + (M[8] * v.z + M[12] * 1.0f), (M[1] * v.x + M[5] * v.y) + (M[9] * v.z + M[13] * 1.0f),
 	        (M[2] * v.x + M[6] * v.y) + (M[10] * v.z + M[14] * 1.0f)};
 }
-__device__ __forceinline__ f3 xform_dir(const float* __restrict__ M, f3 v) {
+__host__ __device__ __forceinline__ f3 xform_dir(const float* __restrict__ M, f3 v) {
 	return {(M[0] * v.x + M[4] * v.y) + (M[8] * v.z + M[12] * 0.0f), (M[1] * v.x + M[5] * v.y) + (M[9] * v.z + M[13] * 0.0f),
 	        (M[2] * v.x + M[6] * v.y) + (M[10] * v.z + M[14] * 0.0f)};
 }

@@ -14,6 +14,7 @@ G[sq3]="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_BRA
 G[sq4]="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_IFETCH"
 G[fetch]="FETCH_SIZE GRBM_GUI_ACTIVE"
 G[write]="WRITE_SIZE TCC_EA0_ATOMIC_sum"
+G[tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum"
 G[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"
 for name in $PASSES; do
   timeout -s KILL 240 rocprofv3 --pmc ${G[$name]} --output-format csv -d $OUT/$name -- python3 bench.py "${BENCH_ARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err || { echo "pass $name failed"; tail -3 $OUT/$name.err; exit 1; }
