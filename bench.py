@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=32)
     ap.add_argument("--bounces", type=int, default=5)
-    ap.add_argument("--queue-gib", type=float, default=16.0)
+    ap.add_argument("--queue-gib", type=float, default=64.0, help="ray queue memory per GPU; larger queues mean fewer, larger launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration; 0 skips it")
     ap.add_argument("--cpu-kind", choices=["port", "reference"], default="port")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel launches with HIP events")

@@ -24,7 +24,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -41,7 +43,7 @@ constexpr int kBlock = 256;  // 4 wave64 per workgroup
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 2  // waves per SIMD the bounce kernel's register budget is sized for
 #endif
-constexpr int kStack = 32;   // per-lane BVH stack slots in LDS (>= ptx::kBvhMaxDepth)
+constexpr int kStack = 30;  // entries per lane; a BVH of depth d needs d - 1 (kBvhMaxDepth = 30), and five blocks of 30 KiB fit the 160 KiB of a CU
 static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
 constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
 constexpr unsigned kMaxBounces = 63;
@@ -1241,6 +1243,8 @@ struct PtxScene {
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
 	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
+	unsigned n_cus = 0, grid_rounds = 3;
+	std::map<const void*, unsigned> resident_blocks;  // per kernel: blocks the device keeps resident at once
 	bool profiling = false;
 	std::vector<hipEvent_t> events;      // pairs, reused from call to call
 	std::vector<unsigned> event_tag;     // kernel kind and depth of pair k
@@ -1375,6 +1379,8 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	sc->n_prims = D->n_prims;
 	sc->n_frames = D->n_frames;
 	sc->grid = prop.multiProcessorCount * 8;
+	sc->n_cus = (unsigned) prop.multiProcessorCount;
+	if (const char* e = std::getenv("PTX_GRID_ROUNDS")) sc->grid_rounds = (unsigned) std::max(1, std::atoi(e));
 
 	// ---- materials, lights
 	std::vector<float4> mats((size_t) D->n_materials * 4);
@@ -1685,10 +1691,23 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	auto hit_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kCountsPerDepth; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
-	auto launch_depth = [&](unsigned d, unsigned grid) -> PtxStatus {
+	// persistent grids: as many blocks as the kernel can keep resident on the device, times
+	// kGridRounds so that blocks which finish early are replaced; never more than `useful`
+	auto grid_of = [&](auto kern, uint64_t useful) -> unsigned {
+		const void* key = reinterpret_cast<const void*>(kern);
+		auto it = sc->resident_blocks.find(key);
+		if (it == sc->resident_blocks.end()) {
+			int per_cu = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+			it = sc->resident_blocks.emplace(key, (unsigned) per_cu * sc->n_cus).first;
+		}
+		return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(useful, (uint64_t) it->second * sc->grid_rounds));
+	};
+	auto launch_depth = [&](unsigned d, uint64_t useful) -> PtxStatus {
 		if (!staged) {
 			HIP_TRY(tick(0, d, true));
 			auto kern = d == 0 ? (ip ? k_bounce<true, true> : k_bounce<true, false>) : (ip ? k_bounce<false, true> : k_bounce<false, false>);
+			const unsigned grid = grid_of(kern, useful);
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(0, d, false));
 			launches += 1;
@@ -1697,16 +1716,16 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		A.shadow_count = shadow_count_of(d);
 		A.hit_count = hit_count_of(d);
 		HIP_TRY(tick(0, d, true));
-		if (d == 0) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, stream, A);
-		else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, stream, A);
+		if (d == 0) hipLaunchKernelGGL(k_trace<true>, dim3(grid_of(k_trace<true>, useful)), dim3(kBlock), 0, stream, A);
+		else hipLaunchKernelGGL(k_trace<false>, dim3(grid_of(k_trace<false>, useful)), dim3(kBlock), 0, stream, A);
 		HIP_TRY(tick(0, d, false));
 		HIP_TRY(tick(1, d, true));
 		auto kern = d == 0 ? (ip ? k_shade<true, true> : k_shade<true, false>) : (ip ? k_shade<false, true> : k_shade<false, false>);
-		hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, A);
+		hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
-			hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(k_shadow, dim3(grid_of(k_shadow, useful)), dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(2, d, false));
 			launches += 1;
 		}
@@ -1783,7 +1802,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			set_depth(d, (unsigned) off, cnt);
-			PtxStatus ls = launch_depth(d, (unsigned) sc->grid);
+			PtxStatus ls = launch_depth(d, ~0ull);
 			if (ls != PTX_OK) return ls;
 			if (last) continue;
 			HIP_TRY(hipMemcpyAsync(tails.data(), count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
@@ -1806,8 +1825,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		A.batch = cnt;
 		for (unsigned d = 0; d <= max_depth; ++d) {
 			set_depth(d, 0, chunk);
-			unsigned grid = d == 0 ? (unsigned) std::min<uint64_t>((cnt + kBlock - 1) / kBlock, (uint64_t) sc->grid) : (unsigned) sc->grid;
-			PtxStatus ls = launch_depth(d, grid);
+			PtxStatus ls = launch_depth(d, d == 0 ? (cnt + kBlock - 1) / kBlock : ~0ull);
 			if (ls != PTX_OK) return ls;
 		}
 		if (max_depth == 0) continue;
