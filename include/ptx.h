@@ -132,7 +132,16 @@ typedef struct PtxRenderParams {
 	uint32_t max_ray_bounces;
 	uint32_t sample_begin, sample_end; /* 0, aa_steps*aa_steps for the whole image */
 	uint32_t pipeline;                 /* PtxPipeline; 0 = the library's default */
+	uint32_t jitter_seed;              /* 0 = the reference's regular grid (sample at the corner of its sub-pixel cell);
+	                                      otherwise each sample moves to a pseudo-random point INSIDE its cell, drawn from a
+	                                      counter-based generator keyed by (seed, pixel, sample) - see ptx_jitter().  No
+	                                      counterpart in the reference, which has no random numbers at all. */
 } PtxRenderParams;
+
+/* The offsets (in units of one sub-pixel cell, each in [0, 1)) jitter_seed != 0 adds to sample
+ * `sample` of pixel `pixel`; the same function the kernels evaluate.  Stateless: any GPU can
+ * produce any sample's offsets, so a sample range renders the same whichever rank takes it. */
+void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx, float* dy);
 
 /*
  * How one depth of the ray tree is run (same rays, same arithmetic per ray either way):

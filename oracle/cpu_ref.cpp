@@ -856,6 +856,29 @@ Ray primary_ray(CameraBasis const& cb, unsigned w, unsigned h, unsigned x, unsig
 	return Ray{{cb.m.c[3].x, cb.m.c[3].y, cb.m.c[3].z}, {d.x, d.y, d.z}};
 }
 
+// Jittered sampling - NOT in the reference (which samples the corner of every sub-pixel cell
+// and has no random numbers): the product offers it as an option, so the checker restates the
+// product's published generator (include/ptx.h, ptx_jitter) to be able to check that mode too.
+// Parity of this mode is pinned by nothing in the reference.
+inline uint32_t mix32(uint32_t x) {
+	x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+	return x;
+}
+inline void jitter_offsets(uint32_t seed, uint32_t pixel, uint32_t sample, float& dx, float& dy) {
+	uint32_t k = mix32(seed) ^ mix32(pixel * 0x9e3779b9u + 0x7f4a7c15u) ^ mix32(sample * 0x85ebca6bu + 0xc2b2ae35u);
+	uint32_t a = mix32(k), b = mix32(k ^ 0x68e31da4u);
+	dx = (float) (a >> 8) * 5.9604644775390625e-08f;
+	dy = (float) (b >> 8) * 5.9604644775390625e-08f;
+}
+Ray jittered_ray(CameraBasis const& cb, unsigned w, unsigned h, unsigned x, unsigned y, int aax, int aay, unsigned aa, float aa_unit, uint32_t seed) {
+	float jx, jy;
+	jitter_offsets(seed, y * w + x, (uint32_t) (aax * (int) aa + aay), jx, jy);
+	V3 pp{x + (aax + jx) * aa_unit - (w * 0.5f), y + (aay + jy) * aa_unit - (h * 0.5f), -cb.dist};
+	V3 nn = normalize(pp);
+	V4 d = mul(cb.m, V4{nn.x, nn.y, nn.z, 0});
+	return Ray{{cb.m.c[3].x, cb.m.c[3].y, cb.m.c[3].z}, {d.x, d.y, d.z}};
+}
+
 // ppmwriter.cpp:41-43: (unsigned) max(0.0, min(255.0 * c, 255.0)) evaluated in double
 inline unsigned char quantise(float c) {
 	double v = std::min(255.0 * c, 255.0);
@@ -903,8 +926,15 @@ void oracle_scene_info(void* s, float* cam10, float* ambient3, int* n_lights, fl
 // ppm_rgb: w*h*3 bytes, rows flipped as the PPM stores them.  counters (optional): 7 x u64
 // {trace rays, shadow rays, shaded hits, sphere tests, box tests, triangle tests, bounds tests}.
 // threads <= 0 => hardware_concurrency (renderer.cpp:39).  Returns wall seconds of the pixel loop.
+double oracle_render_jittered(void* s, unsigned w, unsigned h, unsigned aa, unsigned bounces, int threads, float* color_buffer,
+                              unsigned char* ppm_rgb, uint64_t* counters, uint32_t jitter_seed);
 double oracle_render(void* s, unsigned w, unsigned h, unsigned aa, unsigned bounces, int threads,
                      float* color_buffer, unsigned char* ppm_rgb, uint64_t* counters) {
+	return oracle_render_jittered(s, w, h, aa, bounces, threads, color_buffer, ppm_rgb, counters, 0);
+}
+// the same loop; jitter_seed != 0 moves every sample inside its cell (jittered_ray above)
+double oracle_render_jittered(void* s, unsigned w, unsigned h, unsigned aa, unsigned bounces, int threads, float* color_buffer,
+                              unsigned char* ppm_rgb, uint64_t* counters, uint32_t jitter_seed) {
 	Scene* sc = static_cast<Scene*>(s);
 	Renderer R{*sc, w, h, aa, bounces};
 	CameraBasis cb = camera_basis(sc->camera, w);
@@ -922,7 +952,8 @@ double oracle_render(void* s, unsigned w, unsigned h, unsigned aa, unsigned boun
 			Color acc{};
 			for (int aax = 0; aax < (int) aa; ++aax)
 				for (int aay = 0; aay < (int) aa; ++aay)
-					acc += R.trace(primary_ray(cb, w, h, x, y, aax, aay, aa_unit));
+					acc += R.trace(jitter_seed ? jittered_ray(cb, w, h, x, y, aax, aay, aa, aa_unit, jitter_seed)
+					                           : primary_ray(cb, w, h, x, y, aax, aay, aa_unit));
 			acc *= 1.0f / (aa * aa);
 			// tone map, renderer.cpp:286-291
 			acc.r /= acc.r + 1; acc.g /= acc.g + 1; acc.b /= acc.b + 1;

@@ -47,6 +47,8 @@ class Port:
         L.oracle_leaf_path.argtypes = [C.c_void_p, C.c_int]
         L.oracle_render.restype = C.c_double
         L.oracle_render.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_render_jittered.restype = C.c_double
+        L.oracle_render_jittered.argtypes = L.oracle_render.argtypes + [C.c_uint32]
         L.oracle_sample_colors.argtypes = [C.c_void_p] + [C.c_uint] * 8 + [C.c_void_p]
         L.oracle_ppm_text.restype = C.c_long
         L.oracle_ppm_text.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_long]
@@ -75,11 +77,14 @@ class Port:
         n = self.L.oracle_leaf_count(s)
         return [self.L.oracle_leaf_path(s, i).decode() for i in range(n)]
 
-    def render(self, s, w, h, aa, bounces, threads=0, counters=False):
+    def render(self, s, w, h, aa, bounces, threads=0, counters=False, jitter_seed=0):
         cb = np.zeros((h, w, 3), f32)
         rgb = np.zeros((h, w, 3), np.uint8)
         cnt = np.zeros(7, np.uint64) if counters else None
-        sec = self.L.oracle_render(s, w, h, aa, bounces, threads, _p(cb), _p(rgb), _p(cnt))
+        if jitter_seed:  # the product's optional jittered sampling (nothing in the reference corresponds to it)
+            sec = self.L.oracle_render_jittered(s, w, h, aa, bounces, threads, _p(cb), _p(rgb), _p(cnt), jitter_seed)
+        else:
+            sec = self.L.oracle_render(s, w, h, aa, bounces, threads, _p(cb), _p(rgb), _p(cnt))
         return dict(color=cb, rgb=rgb, seconds=sec, counters=cnt)
 
     def sample_colors(self, s, w, h, aa, bounces, x0, y0, nx, ny):

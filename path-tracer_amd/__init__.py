@@ -25,7 +25,7 @@ STATUS_NAMES = {0: "PTX_OK", 1: "PTX_ERR_INVALID", 2: "PTX_ERR_UNSUPPORTED", 3: 
 # every symbol include/ptx.h declares (checked by tests/test_abi.py)
 PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
-    "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_scene_info",
+    "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_scene_info", "ptx_jitter",
     "ptx_scene_set_profiling",
 ]
 
@@ -67,7 +67,7 @@ class PtxSceneDesc(C.Structure):
 
 class PtxRenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aa_steps", C.c_uint32), ("max_ray_bounces", C.c_uint32),
-                ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("pipeline", C.c_uint32)]
+                ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("pipeline", C.c_uint32), ("jitter_seed", C.c_uint32)]
 
 
 class PtxStats(C.Structure):
@@ -111,6 +111,8 @@ def ptx_lib():
     L.ptx_intersect.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.ptx_primary_hits.argtypes = [vp, C.POINTER(PtxRenderParams), C.c_uint32, vp, vp]
     L.ptx_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.ptx_jitter.restype = None
+    L.ptx_jitter.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ptx_scene_set_profiling.argtypes = [vp, C.c_int]
     L.ptx_scene_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L._typed = True
@@ -151,10 +153,10 @@ def _ptr(a):
 PIPELINES = {"default": 0, "fused": 1, "staged": 2}
 
 
-def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None, pipeline="default"):
+def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0):
     if sample_end is None:
         sample_end = aa_steps * aa_steps
-    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end, PIPELINES[pipeline])
+    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end, PIPELINES[pipeline], jitter_seed)
 
 
 class HostScene:
@@ -234,8 +236,8 @@ class DeviceScene:
         _check(self.L.ptx_scene_info(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
         return dict(n_frames=a.value, n_prims=b.value, n_bvh_nodes=c.value, max_bvh_depth=d.value, device_bytes=e.value)
 
-    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default"):
-        rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline)
+    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0):
+        rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline, jitter_seed)
         color = np.zeros((h, w, 3), np.float32)
         rgb = np.zeros((h, w, 3), np.uint8)
         sec = C.c_double(0)

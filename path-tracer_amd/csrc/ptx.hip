@@ -137,6 +137,8 @@ struct DevCamera {  // Renderer::render's camera basis, framework/renderer.cpp:2
 	float half_w, half_h;
 	uint32_t width, height, aa_steps;
 	double inv_width, inv_aa;  // 1.0 / width, 1.0 / aa_steps (udivmod)
+	uint32_t jitter_seed;      // 0 = regular grid
+	uint32_t pad;
 };
 
 struct RayQueue {  // SoA planes: each store/load is 16 (8) B per lane, contiguous across the wave; 40 B per ray
@@ -686,6 +688,12 @@ __device__ __forceinline__ void make_primary(const DevCamera& cam, unsigned pixe
 	udivmod(s, cam.aa_steps, cam.inv_aa, ax, ay);
 	int aax = (int) ax, aay = (int) ay;
 	f3 pp = {x + aax * cam.aa_unit - cam.half_w, y + aay * cam.aa_unit - cam.half_h, -cam.dist};
+	if (cam.jitter_seed) {  // jittered sampling (not in the reference): a point inside the sample's cell
+		float jx, jy;
+		jitter_offsets(cam.jitter_seed, pixel, s, jx, jy);
+		pp.x = x + (aax + jx) * cam.aa_unit - cam.half_w;
+		pp.y = y + (aay + jy) * cam.aa_unit - cam.half_h;
+	}
 	f3 n = normalize(pp);
 	d = xform_dir(cam.m, n);
 	o = mk(cam.m[12], cam.m[13], cam.m[14]);
@@ -1287,6 +1295,8 @@ void camera_basis(const PtxCamera& c, const PtxRenderParams& rp, DevCamera& out)
 	out.aa_steps = rp.aa_steps;
 	out.inv_width = 1.0 / rp.width;
 	out.inv_aa = 1.0 / rp.aa_steps;
+	out.jitter_seed = rp.jitter_seed;
+	out.pad = 0;
 }
 
 // Bounding sphere of a frame-0 leaf in frame-0 space for may_hit_sphere: (centre, R^2) with R
@@ -1611,6 +1621,13 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	}
 	*out = sc.release();
 	return PTX_OK;
+}
+
+void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx, float* dy) {
+	float x = 0, y = 0;
+	if (jitter_seed) jitter_offsets(jitter_seed, pixel, sample, x, y);
+	if (dx) *dx = x;
+	if (dy) *dy = y;
 }
 
 PtxStatus ptx_scene_set_profiling(PtxScene* scene, int enable) {

@@ -50,6 +50,24 @@ __host__ __device__ __forceinline__ f3 xform_dir(const float* __restrict__ M, f3
 	        (M[2] * v.x + M[6] * v.y) + (M[10] * v.z + M[14] * 0.0f)};
 }
 
+// Counter-based generator for jittered sampling: two 24-bit uniform numbers in [0, 1) from
+// (seed, pixel, sample) through an integer finaliser (xor-shift-multiply rounds).  No state:
+// every sample's offsets can be formed anywhere, in any order.
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+	x ^= x >> 16;
+	x *= 0x7feb352du;
+	x ^= x >> 15;
+	x *= 0x846ca68bu;
+	x ^= x >> 16;
+	return x;
+}
+__host__ __device__ __forceinline__ void jitter_offsets(uint32_t seed, uint32_t pixel, uint32_t sample, float& dx, float& dy) {
+	uint32_t k = mix32(seed) ^ mix32(pixel * 0x9e3779b9u + 0x7f4a7c15u) ^ mix32(sample * 0x85ebca6bu + 0xc2b2ae35u);
+	uint32_t a = mix32(k), b = mix32(k ^ 0x68e31da4u);
+	dx = (float) (a >> 8) * 5.9604644775390625e-08f;  // 2^-24: exact, < 1
+	dy = (float) (b >> 8) * 5.9604644775390625e-08f;
+}
+
 // The intersectors below are written WITHOUT early returns: every lane runs the whole
 // formula and the reference's `return false` conditions are OR-ed into one flag.  The
 // values that survive are computed by the same operations in the same order, so results

@@ -39,7 +39,7 @@ def test_struct_sizes_match_the_header(pt):
     assert ctypes.sizeof(pt.PtxCamera) == 10 * 4
     assert ctypes.sizeof(pt.PtxFrame) == (16 + 16 + 6 + 2) * 4
     assert ctypes.sizeof(pt.PtxPrim) == (4 + 9 + 3 + 32) * 4
-    assert ctypes.sizeof(pt.PtxRenderParams) == 7 * 4
+    assert ctypes.sizeof(pt.PtxRenderParams) == 8 * 4
     assert ctypes.sizeof(pt.PtxStats) == 5 * 8 + 3 * 16 * 8 + 2 * 3 * 16 * 8
 
 

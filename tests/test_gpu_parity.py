@@ -280,3 +280,46 @@ def test_full_size_properties(pt, scenes):
     assert_image_close(color.cpu().numpy().reshape(h, w, 3), a["color"], rgb.cpu().numpy().reshape(h, w, 3), a["rgb"])
     # the background (no hit at any depth) is exactly black, and nothing is NaN
     assert np.isfinite(a["color"]).all() and (a["color"] >= 0).all()
+
+
+def test_jittered_sampling(pt, port, scenes):
+    """jitter_seed != 0 (an option of this library; the reference only has the regular grid):
+    the kernels draw the same per-sample offsets as ptx_jitter() publishes, the image equals
+    the CPU restatement of that sampling to the usual bar, stays within 2/255 RMSE of the
+    grid image at equal spp (64 spp here; the two converge to the same image), and is the sum
+    of its sample ranges whoever renders them."""
+    import ctypes
+    import torch
+    L = pt.ptx_lib()
+    dx, dy = ctypes.c_float(), ctypes.c_float()
+    seen = set()
+    for pix, smp in ((0, 0), (0, 1), (1, 0), (123456, 789)):
+        L.ptx_jitter(7, pix, smp, ctypes.byref(dx), ctypes.byref(dy))
+        assert 0.0 <= dx.value < 1.0 and 0.0 <= dy.value < 1.0
+        seen.add((dx.value, dy.value))
+    assert len(seen) == 4
+    L.ptx_jitter(0, 5, 5, ctypes.byref(dx), ctypes.byref(dy))
+    assert dx.value == 0.0 and dy.value == 0.0
+    w, h, aa, nb = 96, 60, 8, 5
+    ds, s = scenes.device_scene("cornell"), scenes.oracle_scene("cornell")
+    grid = ds.render_image(w, h, aa, nb)
+    ref = port.render(s, w, h, aa, nb, jitter_seed=7)
+    for pipeline in PIPELINES:
+        r = ds.render_image(w, h, aa, nb, pipeline=pipeline, jitter_seed=7)
+        rmse, mx, frac, worst = image_errors(r["color"], ref["color"], r["rgb"], ref["rgb"])
+        # (flat walls: a wall whose value sits on a rounding boundary of the 8-bit quantisation flips
+        #  as a whole with the last bit of the float sum, so the share of differing bytes is not a
+        #  bar here; no byte differs by more than 1 and the floats agree to 1e-5)
+        assert rmse <= RMSE_MAX and mx <= ABS_MAX and worst <= 1, (rmse, mx, frac, worst)
+    other = ds.render_image(w, h, aa, nb, jitter_seed=8)
+    assert not np.array_equal(other["color"], r["color"])
+    rmse = float(np.sqrt(np.mean((r["color"].astype(np.float64) - grid["color"]) ** 2)))
+    assert 0 < rmse <= 2.0 / 255.0, rmse
+    acc = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for b, e in ((0, 3), (3, 41), (41, 64)):
+        ds.render_accumulate(pt.render_params(w, h, aa, nb, b, e, jitter_seed=7), acc.data_ptr(), stream, check_overflow=True)
+    color = torch.empty(h * w * 3, dtype=torch.float32, device="cuda:0")
+    ds.resolve(acc.data_ptr(), w, h, aa * aa, color.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    assert float(np.abs(color.cpu().numpy().reshape(h, w, 3) - r["color"]).max()) <= ABS_MAX
