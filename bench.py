@@ -11,10 +11,17 @@ rank 0 with one RCCL reduce, rank 0 resolves (average, tone map, 8-bit rows).  T
 resident in HBM before the timed region starts; the image stays on the device.
 
 The JSON line also carries
-  roofline      the dominant kernel (the depth-0 bounce kernel): algorithmic bytes per launch
-                (176 B per ray segment + 24 B per shaded hit, rays and hits counted by the
-                kernel itself) / its average launch duration from HIP events recorded on
-                the launch stream during the timed steps, against 8 TB/s;
+  roofline      the dominant kernel - the one with the largest share of the step's time: the
+                depth-0 closest-hit kernel k_trace<true> of the staged pipeline (or the depth-0
+                k_bounce<true> with --pipeline fused): algorithmic bytes per launch / its
+                average launch duration from HIP events recorded on the launch stream during
+                the timed steps, against 8 TB/s.  Algorithmic bytes follow the per-ray model
+                (ray record 48 B written once, read by intersect, read by shade; hit record
+                16 B written, read; 24 B accumulator update per shaded hit): the closest-hit
+                kernel's share is 48 + 16 B per ray it handles, the fused kernel's 176 B per
+                ray segment + 24 B per hit.  `traffic` is the kernel's HBM bytes per launch
+                from the FETCH_SIZE / WRITE_SIZE counter passes kept under profiles/ (taken
+                with scripts/pmc.sh on this same workload), or null when no such file is there;
   cpu_baseline  the CPU oracle (oracle/cpu_ref.cpp, the bit-exact restatement of the
                 reference renderer) timed on this box's host cores on a bounded sample of
                 the same workload (same scene and resolution, fewer samples per pixel).
@@ -75,6 +82,25 @@ def cpu_baseline(args, scene_path):
     samples = w * h * aa * aa
     return {"value": samples / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
             "sample": f"{args.scene} {w}x{h}, aa_steps={aa} ({aa * aa} of {args.aa * args.aa} spp), {nb} bounces, {r['seconds']:.1f} s"}
+
+
+def measured_traffic(args, kernel, launches):
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r01_hbm_traffic.json,
+    written by scripts/pmc_summary.py --traffic), if they were taken on this workload: same scene,
+    size, spp and bounces, hence the same number of launches per step."""
+    path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    w = t.get("_workload", {})
+    if [w.get(k) for k in ("scene", "width", "height", "aa", "bounces", "queue_gib")] != [args.scene, args.width, args.height, args.aa, args.bounces, args.queue_gib]:
+        return None
+    k = t.get(kernel)
+    if not k or "hbm_bytes_per_launch" not in k:
+        return None
+    return k["hbm_bytes_per_launch"]
 
 
 def main():
@@ -179,8 +205,8 @@ def main():
                 bytes0 = BYTES_PER_RAY * (rays0 + shadow0) + BYTES_PER_HIT * hits0
             achieved = bytes0 / (ms0 * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n0, "avg_launch_ms": ms0 / n0,
-                               "algorithmic_bytes_per_launch": bytes0 / n0}
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, "k_trace<true>" if staged else "k_bounce<true, true>", n0),
+                               "launches": n0, "avg_launch_ms": ms0 / n0, "algorithmic_bytes_per_launch": bytes0 / n0}
             tot_ms = sum(sum(r) for r in kms)
             tot_bytes = BYTES_PER_RAY * R + BYTES_PER_HIT * H
             out["kernel_time"] = {"pipeline": "staged" if staged else "fused",

@@ -4,20 +4,24 @@
 // triangle.cpp:56-88 of the reference).
 //
 // Structure of one render
-//   for every batch of primary samples (pixel-major, sample-minor, so the 64 lanes of a
-//   wave are 64 samples of ONE pixel):
-//     k_bounce<depth 0>   generates the primary rays in registers (no primary-ray queue),
-//     k_bounce<depth d>   reads the rays of queue[d-1]; both then, per ray:
-//        closest hit      root leaves in lock step (wave-uniform scalar loads) + one
-//                         BVH2 walk per mesh frame with a per-lane stack in LDS
-//        shade            Phong + one any-hit shadow walk per light (inline, no shadow queue)
-//        emit             <= 2 weighted child rays (reflection / refraction) appended to
-//                         queue[d] with one wave64 ballot + one atomic per wave
-//        accumulate       weight * local colour, segmented wave reduction per pixel, then
-//                         one float atomicAdd per (pixel run, channel)
-//   k_resolve             accum / spp -> tone map -> float colour buffer + flipped 8-bit rows
-// No host synchronisation inside a render: ray counts stay in device memory and every
-// launch is a fixed persistent grid that strides over the count it reads.
+//   for every chunk of primary samples (pixel-major, sample-minor, so the 64 lanes of a
+//   wave are 64 samples of ONE pixel), for every depth d of the ray tree:
+//     k_trace    closest hit of every ray of depth d (d = 0: rays generated in registers, no
+//                primary-ray queue; d > 0: read from queue[d-1]): frame-0 leaves in lock step
+//                (wave-uniform scalar loads, a bounding-sphere filter in front of each exact
+//                test) + one BVH2 walk per mesh frame with a per-lane stack in LDS; the hits
+//                are compacted into a list of 16-byte records
+//     k_shade    one lane per hit: surface point, Phong terms, <= 2 weighted child rays
+//                (reflection / refraction) appended to queue[d], one shadow-ray record per
+//                light appended to the shadow queue, ambient term accumulated
+//     k_shadow   any-hit walk per shadow ray; an unblocked ray adds its contribution
+//     (or k_bounce: all of that in one kernel per depth, the fused pipeline)
+//     appends    one wave64 ballot + ONE returning atomic per wave and step
+//     accumulate segmented wave reduction per pixel, then one float atomicAdd per
+//                (pixel run, channel)
+//   k_resolve    accum / spp -> tone map -> float colour buffer + flipped 8-bit rows
+// Ray counts stay in device memory: every launch is a persistent grid that strides over the
+// count it reads; the host looks at the counters once per chunk of primary samples.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,0 +1,19 @@
+#!/bin/bash
+# The round's measurement record (run on the GPU box from the repo root):
+#   1. bench.py with its default arguments            -> $OUT/bench.json
+#   2. rocprofv3 --kernel-trace --stats of the bench  -> $OUT/kernel_stats.csv (+ bench line)
+#   3. counter passes, one group per run              -> $OUT/pmc/, summary + HBM traffic per launch
+# usage: scripts/profile_round.sh gpurun_out/r1
+set -u
+export TMPDIR=/tmp
+OUT=$PWD/$1
+mkdir -p $OUT
+timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+echo "bench ok"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-seconds 0 > $OUT/bench_traced.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+echo "trace ok"
+PASSES="sq1 sq2 sq4 tcp fetch write" scripts/pmc.sh $1/pmc --steps 1 --warmup 0 --cpu-seconds 0 --no-profile || exit 1
+python3 scripts/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt
+python3 scripts/pmc_summary.py --traffic $OUT/pmc example.sdf 1920 1080 32 5 64 > $OUT/hbm_traffic.json
+echo "pmc ok"
