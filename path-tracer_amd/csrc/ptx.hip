@@ -367,19 +367,20 @@ __device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, 
 	}
 }
 
-// scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103
-__device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
+// scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103.
+// In parts, so that the closest-hit kernel can run the mesh walks of several steps together
+// (see k_trace):
+//   closest_root    root bounds + the leaves of frame 0; false when the ray misses the root bounds
+//   frame_mask      bit f set: the ray enters the bounds of mesh frame f (frames 1..31; bit 0
+//                   set: there are frames beyond 31, which closest_frames tests itself)
+//   closest_frames  the mesh frames; with `known` a frame below 32 is walked iff its bit is set
+__device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, const RayPre& pre, Hit& best) {
 	best.t = kInf;
 	best.id = -1;
 	best.frame = 0;
 	best.slot = 0;
 	float unused;
-	RayPre pre = ray_pre(S, d);
-	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return;
-#if defined(PTX_EXP_TRACE) && PTX_EXP_TRACE == 1
-	best.t = unused;
-	return;
-#endif
+	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return false;
 	for (int i = 0; i < S.n_root_prims; ++i) {
 		if (!__ballot(may_hit_sphere(kload(S.root_bound_k + i), o, d, pre.dd))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
@@ -390,17 +391,37 @@ __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int
 		best.id = better ? P.id : best.id;
 		best.slot = better ? i : best.slot;
 	}
-#if defined(PTX_EXP_TRACE) && PTX_EXP_TRACE == 2
-	return;
-#endif
+	return true;
+}
+__device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, const RayPre& pre) {
+	unsigned mask = S.n_frames > 32 ? 1u : 0u;
+	float unused;
+	const int nf = S.n_frames < 32 ? S.n_frames : 32;
+	for (int f = 1; f < nf; ++f) {
+		const DevFrame F = kload(S.frames_k + f);
+		if (!F.has_prims) continue;
+		if (box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) mask |= 1u << f;
+	}
+	return mask;
+}
+template <bool KNOWN>
+__device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, const RayPre& pre, unsigned known, int* __restrict__ stk, Hit& best) {
+	float unused;
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
-		if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
+		if (KNOWN && f < 32) {
+			if (!(known >> f & 1u)) continue;
+		} else if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
 		f3 lo, ld;
 		frame_ray(S, F, f, o, d, lo, ld);
 		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f);
 	}
+}
+__device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
+	const RayPre pre = ray_pre(S, d);
+	if (!closest_root(S, o, d, pre, best)) return;
+	closest_frames<false>(S, o, d, pre, 0u, stk, best);
 }
 
 // find_light_block(...).does_intersect, framework/renderer.cpp:168-175: the closest hit
@@ -927,54 +948,107 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 // waves per SIMD of the fused kernel.  k_trace leaves a compacted list of 16-byte hit
 // records (most primary rays of a typical frame hit nothing), so k_shade runs full waves of
 // hits only and fetches (or, at depth 0, regenerates) just the rays that hit.
+// Only some of a step's 64 rays get as far as a mesh; the others are settled by the leaves of
+// frame 0 or miss every mesh's bounds.  Walking a BVH with the few that remain leaves most
+// lanes idle (measured: 13 of 64 on the incoherent depths), so unless most of the step goes
+// on (kWalkNow lanes) the wave parks those rays - ray index and the best hit so far - in a
+// small ring in LDS and walks once 64 of them have gathered, with every lane busy at the start.
+constexpr unsigned kRing = 128;    // parked rays per wave
+constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
 template <bool PRIMARY>
 __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ unsigned pfx[kNQ + 1];
+	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
 	int* stk = lds_stack + threadIdx.x;
+	volatile float4* ring = ring_mem + (threadIdx.x >> 6) * kRing;
 	const unsigned lane = lane_id();
 	const unsigned n = launch_input<PRIMARY>(A, pfx);
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	unsigned cnt_trace = 0;
-	// The slots of a step's hit records come from a returning atomic, whose round trip to the
-	// memory side is about as long as a short traversal.  The records of step k are therefore
-	// kept in registers and written during step k + 1, when the answer has long arrived.
-	bool pend = false, p_hit = false;
-	float4 p_rec = make_float4(0, 0, 0, 0);
-	unsigned p_slot0 = 0, p_rank = 0, p_total = 0, p_q = 0;
-	auto flush = [&]() {
-		const unsigned slot0 = __shfl(p_slot0, 0);
-		const unsigned my = slot0 + p_rank;
-		if (p_hit && my < A.hit_subcap) A.hits[(size_t) p_q * A.hit_subcap + my] = p_rec;
-		if (lane == 0 && slot0 + p_total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);
+	unsigned parked = 0, emits = wave;  // the same in every lane
+	// the hit records of the lanes with `hit`, compacted, into one sub-list (keeping them in
+	// registers until the atomic's answer has arrived, a step later, was measured: no gain)
+	auto emit = [&](bool hit, const Hit& h, unsigned i) {
+		const unsigned long long m = __ballot(hit);
+		if (!m) return;
+		const unsigned total = __builtin_popcountll(m);
+		const unsigned q = sub_queue_of((unsigned long long) emits++ << 6, total);
+		unsigned slot0 = 0;
+		if (lane == 0) slot0 = atomicAdd(A.hit_count + q * kCountPad, total);
+		slot0 = __shfl(slot0, 0);
+		const unsigned my = slot0 + __builtin_popcountll(m & lanes_below(lane));
+		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
+		const int where = h.frame == 0 ? h.slot : -h.frame;
+		if (hit && my < A.hit_subcap)
+			A.hits[(size_t) q * A.hit_subcap + my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(i));
+		if (lane == 0 && slot0 + total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);
+	};
+	// the mesh walks of the `count` most recently parked rays
+	auto walk_parked = [&](unsigned count) {
+		Hit h;
+		h.id = -1;
+		h.frame = 0;
+		h.slot = 0;
+		h.t = kInf;
+		unsigned i = 0;
+		if (lane < count) {
+			const volatile float4* rq = ring + (parked - count + lane);
+			h.t = rq->x;
+			h.id = __float_as_int(rq->y);
+			h.slot = __float_as_int(rq->z);
+			i = __float_as_uint(rq->w);
+			f3 o, d, w;
+			unsigned pix;
+			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+			const RayPre pre = ray_pre(A.S, d);
+			closest_frames<false>(A.S, o, d, pre, 0u, stk, h);
+		}
+		parked -= count;
+		emit(h.id >= 0, h, i);
 	};
 	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
 		unsigned i = (unsigned) base + lane;
 		Hit h;
 		h.id = -1;
+		h.frame = 0;
+		h.slot = 0;
+		h.t = kInf;
+		f3 o = {0, 0, 0}, d = {0, 0, 1}, w;
+		unsigned pix, frames = 0;
+		RayPre pre = ray_pre(A.S, d);
 		if (i < n) {
-			f3 o, d, w;
-			unsigned pix;
 			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
-			trace_closest(A.S, o, d, stk, h);
+			pre = ray_pre(A.S, d);
+			if (closest_root(A.S, o, d, pre, h)) frames = frame_mask(A.S, o, d, pre);
 			++cnt_trace;
 		}
-		if (pend) flush();
-		const bool hit = h.id >= 0;
-		const unsigned long long m = __ballot(hit);
-		pend = m != 0;
-		if (!pend) continue;
-		p_total = __builtin_popcountll(m);
-		p_q = sub_queue_of(base, p_total);
-		if (lane == 0) p_slot0 = atomicAdd(A.hit_count + p_q * kCountPad, p_total);
-		p_rank = __builtin_popcountll(m & lanes_below(lane));
-		p_hit = hit;
-		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
-		const int where = h.frame == 0 ? h.slot : -h.frame;
-		p_rec = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(i));
+		bool park = frames != 0;
+		const unsigned long long m = __ballot(park);
+		const unsigned cnt = __builtin_popcountll(m);
+		// most of the wave goes on to a mesh (or these are primary rays, neighbours in the image):
+		// walk here, the rays are in registers
+		const bool walk_now = PRIMARY || cnt >= kWalkNow;
+		if (walk_now) {
+			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h);
+			park = false;
+		}
+		emit(h.id >= 0 && !park, h, i);
+		if (cnt && !walk_now) {
+			if (parked + cnt > kRing) walk_parked(parked < 64 ? parked : 64);
+			if (park) {
+				volatile float4* rq = ring + (parked + __builtin_popcountll(m & lanes_below(lane)));
+				rq->x = h.t;
+				rq->y = __int_as_float(h.id);
+				rq->z = __int_as_float(h.slot);
+				rq->w = __uint_as_float(i);
+			}
+			parked += cnt;
+			if (parked >= 64) walk_parked(64);
+		}
 	}
-	if (pend) flush();
+	if (parked) walk_parked(parked);
 	wave_stats(A, wave, cnt_trace, 0, 0);
 }
 
