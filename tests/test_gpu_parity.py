@@ -323,3 +323,44 @@ def test_jittered_sampling(pt, port, scenes):
     ds.resolve(acc.data_ptr(), w, h, aa * aa, color.data_ptr(), None, stream)
     torch.cuda.synchronize()
     assert float(np.abs(color.cpu().numpy().reshape(h, w, 3) - r["color"]).max()) <= ABS_MAX
+
+
+def test_many_meshes(pt, port, tmp_path):
+    """36 mesh frames (more than the 31 whose bounds tests fit the closest-hit kernel's bit
+    mask), overlapping bounds, a mirror sphere to send incoherent rays through them."""
+    import shutil
+    for k in range(36):
+        shutil.copy(pt.SDF_DIR + "/sword.obj", tmp_path / f"m{k:02d}.obj")
+    shutil.copy(pt.SDF_DIR + "/sword.mtl", tmp_path / "sword.mtl")
+    lines = ["define material mirror 0 0 0 0 0 0 1 1 1 50 0.9 1 1", "define material wall .8 .8 .8 .8 .8 .8 0 0 0 0 0 1 1",
+             "define shape sphere ball 0 1 -2 1.2 mirror", "define shape box floor -20 -3 -30 20 -2.5 10 wall"]
+    for k in range(36):
+        lines.append(f"define shape obj m{k:02d}")
+    lines += ["define light sun 5 20 10 .8 .8 .8 1", "define ambient amb 1 1 1 0.2", "define camera eye 60 0 1 8 0 -5 0"]
+    for k in range(36):
+        x, z = (k % 6 - 2.5) * 1.3, -(k // 6) * 1.5
+        lines.append(f"transform m{k:02d} translate {x} {0.2 * (k % 3)} {z}")
+        if k % 4 == 1:
+            lines.append(f"transform m{k:02d} rotate {10 * k} 20 0")
+        if k % 5 == 2:
+            lines.append(f"transform m{k:02d} scale 1.5 0.7 1.1")
+    sdf = tmp_path / "swords.sdf"
+    sdf.write_text("\n".join(lines) + "\n")
+    hs = pt.HostScene(str(sdf), str(tmp_path) + "/")
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    assert ds.info()["n_frames"] == 37
+    s = port.load(str(sdf), str(tmp_path) + "/")
+    from oracle_lib import random_rays
+    o, d = port.primary_rays(s, 160, 100, 1)
+    o2, d2 = random_rays(20000, 7)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    assert m.sum() > 5000
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    ref = port.render(s, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
