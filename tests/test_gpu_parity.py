@@ -364,3 +364,28 @@ def test_many_meshes(pt, port, tmp_path):
     for pipeline in PIPELINES:
         r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
         assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+
+
+def test_deepest_ray_trees(pt, port, tmp_path):
+    """max_ray_bounces at the library's limit (63) in a hall of mirrors (one child per hit), with
+    the smallest queue memory: 64 queues share it, every depth is still traced, nothing is dropped."""
+    sdf = tmp_path / "mirrors.sdf"
+    sdf.write_text("define material mirror 0.1 0.1 0.1 0.2 0.2 0.2 0.95 0.95 0.95 20 1 1 1\n"
+                   "define material red 1 0 0 1 0 0 1 1 1 10 0 1 1\n"
+                   "define shape box left -6 -5 -30 -5 5 10 mirror\ndefine shape box right 5 -5 -30 6 5 10 mirror\n"
+                   "define shape box back -6 -5 -31 6 5 -30 mirror\ndefine shape box front -6 -5 10 6 5 11 mirror\n"
+                   "define shape box floor -6 -6 -31 6 -5 11 mirror\ndefine shape box ceil -6 5 -31 6 6 11 mirror\n"
+                   "define shape sphere ball 1 0 -8 1.5 red\n"
+                   "define light l 0 4 0 .8 .8 .8 1\ndefine ambient amb 1 1 1 0.1\ndefine camera eye 70 0 0 5 20 0 0\n")
+    hs = pt.HostScene(str(sdf))
+    s = port.load(str(sdf))
+    small = pt.DeviceScene(hs, 0, 1)
+    w, h, aa, nb = 40, 24, 2, 63
+    ref = port.render(s, w, h, aa, nb, counters=True)
+    for pipeline in PIPELINES:
+        r = small.render_image(w, h, aa, nb, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+        assert r["stats"]["trace_rays"] > 20 * w * h * aa * aa      # the trees really are deep
+        assert r["stats"]["trace_rays"] <= int(ref["counters"][0])
+    with pytest.raises(pt.PtxError):
+        small.render_image(w, h, aa, 64)
