@@ -80,7 +80,7 @@ struct DevRootPrim {  // a leaf of frame 0, tested by every ray: 64 B, fetched w
 	int32_t kind_flags;  // PtxPrimKind | kPlain
 	float p[9];          // sphere: c, r | box: lo, hi | triangle: v0, e1, e2
 	int32_t id;
-	int32_t xform;       // index into DevScene::xforms when the transform is not a pure translation
+	int32_t xform;       // index into DevScene::xforms (= the leaf's own slot: one entry per frame-0 leaf)
 	int32_t pad;
 };
 struct DevXform {  // full matrices of a leaf whose transform rotates or scales
@@ -88,7 +88,7 @@ struct DevXform {  // full matrices of a leaf whose transform rotates or scales
 	float w[16];
 };
 struct DevRootShade {  // what shading needs of a frame-0 leaf, per root slot
-	float tw[3];  // translation column of world_transform_
+	float tw[3];  // translation column of world_transform_ (kept for inspection; shading uses the full matrices)
 	int32_t material;
 	float n[3];   // triangle: n_
 	int32_t levels_in;
@@ -269,10 +269,8 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 				const float4* tr = tris + (size_t) (first + k) * 3;
 				float4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
 				float t;
-#if !defined(PTX_NO_TRI_EARLY)
 				// most tests end at the first barycentric coordinate: when they do so for the whole wave, skip the rest
 				if (!__ballot(tri_u_ok(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d))) continue;
-#endif
 				if (tri_t(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, t)) {
 					if (ANY) {
 						if (t <= range) return true;
@@ -817,10 +815,7 @@ __device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* p
 
 // Sub-queue that takes the records a wave emits for the step starting at ray `base` of a
 // launch: the steps go round the sub-queues.
-__device__ __forceinline__ unsigned sub_queue_of(unsigned long long base, unsigned total) {
-	(void) total;
-	return (unsigned) (base >> 6) & (kNQ - 1);
-}
+__device__ __forceinline__ unsigned sub_queue_of(unsigned long long base) { return (unsigned) (base >> 6) & (kNQ - 1); }
 
 // wave64 ballot compaction of up to two records per lane into sub-queue q of a queue: the
 // records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.  The
@@ -837,7 +832,7 @@ __device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned long 
 	R.m2 = __ballot(live2);
 	R.slot0 = 0;
 	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
-	R.q = sub_queue_of(base, total);
+	R.q = sub_queue_of(base);
 	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + R.q * kCountPad, total);
 	return R;
 }
@@ -974,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		const unsigned long long m = __ballot(hit);
 		if (!m) return;
 		const unsigned total = __builtin_popcountll(m);
-		const unsigned q = sub_queue_of((unsigned long long) emits++ << 6, total);
+		const unsigned q = sub_queue_of((unsigned long long) emits++ << 6);
 		unsigned slot0 = 0;
 		if (lane == 0) slot0 = atomicAdd(A.hit_count + q * kCountPad, total);
 		slot0 = __shfl(slot0, 0);
