@@ -231,6 +231,16 @@ PtxStatus ptx_primary_hits(PtxScene* scene, const PtxRenderParams* params, uint3
 PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 
 /*
+ * The same rows as a binary PPM ("P6", 3 bytes per pixel instead of up to 12 characters), and
+ * the float colour buffer (y up, as ptx_render_image returns it) as a little-endian PFM
+ * ("PF", rows bottom to top, which is the buffer's own order).  No counterpart in the
+ * reference, whose only writer is the ASCII one above: at 3840x2160 that text is about
+ * 100 MB and takes longer to write than the image takes to render.
+ */
+PtxStatus ptx_write_ppm_binary(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+PtxStatus ptx_write_pfm(const char* path, const float* color, uint32_t width, uint32_t height);
+
+/*
  * Profiling on: ptx_render_accumulate brackets every bounce-kernel launch with a pair of
  * HIP events on the caller's stream and reports per-depth kernel time in PtxStats (which
  * then must be requested).  Off by default.  No counterpart in the reference, whose only

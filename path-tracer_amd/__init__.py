@@ -25,7 +25,7 @@ STATUS_NAMES = {0: "PTX_OK", 1: "PTX_ERR_INVALID", 2: "PTX_ERR_UNSUPPORTED", 3: 
 # every symbol include/ptx.h declares (checked by tests/test_abi.py)
 PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
-    "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_scene_info", "ptx_jitter",
+    "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_write_ppm_binary", "ptx_write_pfm", "ptx_scene_info", "ptx_jitter",
     "ptx_scene_set_profiling",
 ]
 
@@ -111,6 +111,8 @@ def ptx_lib():
     L.ptx_intersect.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     L.ptx_primary_hits.argtypes = [vp, C.POINTER(PtxRenderParams), C.c_uint32, vp, vp]
     L.ptx_write_ppm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.ptx_write_ppm_binary.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.ptx_write_pfm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.ptx_jitter.restype = None
     L.ptx_jitter.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ptx_scene_set_profiling.argtypes = [vp, C.c_int]
@@ -279,6 +281,18 @@ def write_ppm(path, rgb):
     h, w, _ = rgb.shape
     rgb = np.ascontiguousarray(rgb, np.uint8)
     _check(ptx_lib().ptx_write_ppm(os.fspath(path).encode(), _ptr(rgb), w, h))
+
+
+def write_ppm_binary(path, rgb):
+    h, w, _ = rgb.shape
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    _check(ptx_lib().ptx_write_ppm_binary(os.fspath(path).encode(), _ptr(rgb), w, h))
+
+
+def write_pfm(path, color):
+    h, w, _ = color.shape
+    color = np.ascontiguousarray(color, np.float32)
+    _check(ptx_lib().ptx_write_pfm(os.fspath(path).encode(), _ptr(color), w, h))
 
 
 def device_count():

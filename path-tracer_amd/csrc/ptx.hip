@@ -2131,4 +2131,25 @@ PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t w, uint3
 	return ok ? PTX_OK : fail(PTX_ERR_INVALID, std::string("short write to ") + path);
 }
 
+static PtxStatus write_blob(const char* path, const std::string& header, const void* data, size_t bytes) {
+	FILE* f = std::fopen(path, "wb");
+	if (!f) return fail(PTX_ERR_INVALID, std::string("cannot open ") + path);
+	bool ok = std::fwrite(header.data(), 1, header.size(), f) == header.size();
+	ok = ok && std::fwrite(data, 1, bytes, f) == bytes;
+	ok = (std::fclose(f) == 0) && ok;
+	return ok ? PTX_OK : fail(PTX_ERR_INVALID, std::string("short write to ") + path);
+}
+
+PtxStatus ptx_write_ppm_binary(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+	if (!path || !rgb8) return fail(PTX_ERR_INVALID, "path/rgb8 is NULL");
+	return write_blob(path, "P6\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n", rgb8, (size_t) w * h * 3);
+}
+
+PtxStatus ptx_write_pfm(const char* path, const float* color, uint32_t w, uint32_t h) {
+	if (!path || !color) return fail(PTX_ERR_INVALID, "path/color is NULL");
+	const uint16_t probe = 1;
+	if (*reinterpret_cast<const uint8_t*>(&probe) != 1) return fail(PTX_ERR_UNSUPPORTED, "big-endian host");
+	return write_blob(path, "PF\n" + std::to_string(w) + " " + std::to_string(h) + "\n-1.0\n", color, (size_t) w * h * 3 * sizeof(float));
+}
+
 }  // extern "C"

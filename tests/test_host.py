@@ -91,6 +91,27 @@ def test_ppm_text_is_byte_identical(pt, port, tmp_path):
         assert text.startswith(b"P3 %d %d 255 \n" % (g["rgb"].shape[1], g["rgb"].shape[0]))
 
 
+def test_binary_writers(pt, tmp_path):
+    """P6 and PFM carry the same rows / the same floats as the buffers handed in."""
+    import numpy as np
+    g = load_golden("cornell")
+    rgb, color = g["rgb"], g["color"]
+    h, w, _ = rgb.shape
+    p6 = tmp_path / "a.ppm"
+    pt.write_ppm_binary(p6, rgb)
+    raw = p6.read_bytes()
+    head = b"P6\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(head) and raw[len(head):] == rgb.tobytes()
+    pf = tmp_path / "a.pfm"
+    pt.write_pfm(pf, color)
+    raw = pf.read_bytes()
+    head = b"PF\n%d %d\n-1.0\n" % (w, h)
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(h, w, 3).view(np.uint32), color.view(np.uint32))
+    with pytest.raises(pt.PtxError):
+        pt.write_pfm(tmp_path / "no_such_dir" / "x.pfm", color)
+
+
 def test_sample_range_partition(pt):
     from importlib import import_module
     dist = import_module("path-tracer_amd.dist")
