@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=32)
     ap.add_argument("--bounces", type=int, default=5)
-    ap.add_argument("--queue-gib", type=float, default=64.0, help="ray queue memory per GPU; larger queues mean fewer, larger launches")
+    ap.add_argument("--queue-gib", type=float, default=96.0, help="ray queue memory per GPU; larger queues mean fewer, larger launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration; 0 skips it")
     ap.add_argument("--cpu-kind", choices=["port", "reference"], default="port")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel launches with HIP events")
@@ -128,7 +128,19 @@ def main():
 
     scene_path = os.path.join(pt.SDF_DIR, args.scene)
     host = pt.HostScene(scene_path)
-    ds = pt.DeviceScene(host, local_rank, int(args.queue_gib * (1 << 30)))
+    # the queue block is the only large allocation; if the device cannot give that much (other
+    # tenants), take half, and so on: smaller queues only mean more, smaller launches
+    queue_gib = args.queue_gib
+    while True:
+        try:
+            ds = pt.DeviceScene(host, local_rank, int(queue_gib * (1 << 30)))
+            break
+        except pt.PtxError as e:
+            if "NOMEM" not in str(e) or queue_gib <= 1.0:
+                raise
+            queue_gib /= 2
+            print(f"note: rank {rank}: queue allocation failed, retrying with {queue_gib} GiB", file=sys.stderr)
+    args.queue_gib = queue_gib
     profile = not args.no_profile
     ds.set_profiling(profile)
 
@@ -176,7 +188,7 @@ def main():
             "metric": "path samples/sec", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (scene file shipped with the reference; regular sample grid, no RNG)",
-            "config": {"workload": f"{args.scene} {w}x{h}, aa_steps={aa} ({spp} spp), max_ray_bounces={nb}",
+            "config": {"workload": f"{args.scene} {w}x{h}, aa_steps={aa} ({spp} spp), max_ray_bounces={nb}", "queue_gib": queue_gib,
                        "samples_per_step": samples_per_step, "parallelism": f"sample-range x{world}, one RCCL sum-reduce per image"},
         }
         # ---- work done by this rank in the last step (the kernels count it themselves)

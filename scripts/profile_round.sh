@@ -15,5 +15,5 @@ cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 echo "trace ok"
 PASSES="sq1 sq2 sq4 tcp fetch write" scripts/pmc.sh $1/pmc --steps 1 --warmup 0 --cpu-seconds 0 --no-profile || exit 1
 python3 scripts/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt
-python3 scripts/pmc_summary.py --traffic $OUT/pmc example.sdf 1920 1080 32 5 64 > $OUT/hbm_traffic.json
+python3 scripts/pmc_summary.py --traffic $OUT/pmc example.sdf 1920 1080 32 5 96 > $OUT/hbm_traffic.json
 echo "pmc ok"
