@@ -1664,7 +1664,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
 	if (queue_bytes == 0) queue_bytes = 4ull << 30;
 	uint64_t cap = queue_bytes / 48;
-	cap = std::min<uint64_t>(cap, 1ull << 31);
+	cap = std::min<uint64_t>(cap, 1ull << 33);  // 384 GiB: above any device; each queue is limited on its own (64 sub-queues of at most 2^25 records)
 	cap = std::max<uint64_t>(cap, 1ull << 21);  // 96 MiB: enough for one sub-queued queue per depth at the deepest tree allowed
 	cap &= ~127ull;
 	sc->qrays = cap;
