@@ -38,1240 +38,9 @@
 #include "ptx.h"
 #include "ptx_bvh.hpp"
 #include "ptx_device.hpp"
-
-using namespace ptxd;
+#include "ptx_kernels.hpp"
 
 namespace {
-
-constexpr int kBlock = 256;  // 4 wave64 per workgroup
-#ifndef PTX_MIN_WAVES
-#define PTX_MIN_WAVES 2  // waves per SIMD the bounce kernel's register budget is sized for
-#endif
-constexpr int kStack = 30;  // entries per lane; a BVH of depth d needs d - 1 (kBvhMaxDepth = 30), and five blocks of 30 KiB fit the 160 KiB of a CU
-static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
-constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
-constexpr unsigned kMaxBounces = 63;
-// A ray queue is cut into kNQ sub-queues, each with its own tail counter on its own 128-B
-// line.  A wave appends the children of its k-th 64-ray step to sub-queue (k mod kNQ) with
-// one returning atomic.  With ONE tail word every wave of the chip queues up behind the same
-// address (adds to one word retire one at a time, roughly 10 ns each, which made the append
-// the most expensive step of a bounce); spread over 64 words they proceed in parallel, and
-// because consecutive steps go to consecutive sub-queues every sub-queue fills evenly.
-constexpr unsigned kNQ = 64;
-constexpr unsigned kCountPad = 32;  // words between two tail counters
-constexpr unsigned kCountsPerDepth = kNQ * kCountPad;
-constexpr size_t kCountBytes = (size_t) 3 * (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);  // ray-queue tails, shadow-queue tails, hit-list tails
-
-// ---------------------------------------------------------------------------
-// device scene
-// ---------------------------------------------------------------------------
-// pointer to read-only scene data as the DEVICE pass sees it (constant address space, which
-// lets uniform reads become scalar loads); the host pass only stores the address
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PTX_KPTR(T) const __attribute__((address_space(4))) T*
-#else
-#define PTX_KPTR(T) const T*
-#endif
-
-constexpr int kPlain = 1 << 8;  // the shape's own transform is a pure translation: local = x + t, bit for bit
-
-struct DevRootPrim {  // a leaf of frame 0, tested by every ray: 64 B, fetched with one wave-uniform scalar load
-	float tinv[3];       // translation column of world_transform_inv_
-	int32_t kind_flags;  // PtxPrimKind | kPlain
-	float p[9];          // sphere: c, r | box: lo, hi | triangle: v0, e1, e2
-	int32_t id;
-	int32_t xform;       // index into DevScene::xforms (= the leaf's own slot: one entry per frame-0 leaf)
-	int32_t pad;
-};
-struct DevXform {  // full matrices of a leaf whose transform rotates or scales
-	float winv[16];
-	float w[16];
-};
-struct DevRootShade {  // what shading needs of a frame-0 leaf, per root slot
-	float tw[3];  // translation column of world_transform_ (kept for inspection; shading uses the full matrices)
-	int32_t material;
-	float n[3];   // triangle: n_
-	int32_t levels_in;
-};
-struct DevFrame {  // a mesh Composite with its own transform and bounds: 64-B head + matrices
-	float bmin[3];
-	int32_t bvh_root;   // child reference, node indices relative to node_base
-	float bmax[3];
-	int32_t node_base;  // first float4 of this frame's nodes
-	float tinv[3];      // translation column of world_transform_inv_
-	int32_t tri_base;   // first float4 of this frame's triangle records
-	int32_t levels_up;
-	int32_t has_prims;
-	int32_t plain;      // transform is a pure translation
-	int32_t pad;
-};
-struct Mat16 {
-	float m[16];
-};
-struct DevScene {
-	const DevRootPrim* root_prims;
-	const DevRootShade* root_shade;
-	const DevXform* xforms;
-	const DevFrame* frames;
-	const Mat16* frame_winv;
-	const Mat16* frame_w;
-	const float4* nodes;      // 4 float4 per node
-	const float4* tris;       // 3 float4 per triangle: (v0, e1.x) (e1.yz, e2.xy) (e2.z, id, -, -)
-	const float4* prim_info;  // per prim id: (n.x, n.y, n.z, bits(material | levels_in << 16))
-	const float4* materials;  // 4 float4 per PRIM id (its material, so that a hit needs no second, dependent fetch):
-	                          // (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
-	const float4* lights;     // 2 float4 per light: (pos, -) (intensity, -)
-	// the same tables once more, for the wave-uniform reads (kload)
-	PTX_KPTR(DevRootPrim) root_prims_k;
-	PTX_KPTR(DevXform) xforms_k;
-	PTX_KPTR(DevFrame) frames_k;
-	PTX_KPTR(Mat16) frame_winv_k;
-	PTX_KPTR(float4) lights_k;
-	PTX_KPTR(float4) root_bound_k;  // per frame-0 leaf: bounding sphere in frame-0 space (centre, padded radius squared)
-	int32_t n_root_prims, n_frames, n_lights, n_prims;
-	int32_t has_plain_sphere;
-	float ambient[3];
-	float root_min[3], root_max[3];
-};
-
-struct DevCamera {  // Renderer::render's camera basis, framework/renderer.cpp:27-37
-	float m[16];    // trans_mat columns u, v, -dir, pos
-	float dist;     // img_plane_dist
-	float aa_unit;  // 1.0f / aa_steps
-	float half_w, half_h;
-	uint32_t width, height, aa_steps;
-	double inv_width, inv_aa;  // 1.0 / width, 1.0 / aa_steps (udivmod)
-	uint32_t jitter_seed;      // 0 = regular grid
-	uint32_t pad;
-};
-
-struct RayQueue {  // SoA planes: each store/load is 16 (8) B per lane, contiguous across the wave; 40 B per ray
-	float4* a;     // (o.x, o.y, o.z, d.x)
-	float4* b;     // (d.y, d.z, w.r, w.g)
-	float2* c;     // (w.b, bits(pixel))
-};
-
-struct Hit {
-	float t;
-	int32_t id;     // prim id (index into PtxSceneDesc::prims), -1 = miss
-	int32_t frame;  // 0 = root leaf
-	int32_t slot;   // root leaf: index into root_prims
-};
-
-struct Counters {  // cumulative over one ptx_render_accumulate (filled by k_stats_reduce)
-	unsigned long long trace_rays, shadow_rays, shaded_hits, overflow;
-	unsigned long long per_depth[kMaxDepthSlots];
-	unsigned long long per_depth_shadow[kMaxDepthSlots];
-	unsigned long long per_depth_hits[kMaxDepthSlots];
-};
-// Work counters are kept per wave: stat[(depth_slot * kStatWaves + wave) * 4 + {trace, shadow,
-// hits}], each wave adding to its own words with plain loads and stores.  Thousands of waves
-// adding to ONE word with atomics serialise at the memory side (about 10 ns per add), which
-// costs more than the rays they count; a wave's own words are touched by nobody else during
-// a launch, and launches on one stream run in order.
-constexpr unsigned kStatWaves = 16384;
-constexpr size_t kStatBytes = (size_t) kMaxDepthSlots * kStatWaves * 4 * sizeof(unsigned long long);
-
-__device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
-
-// Wave-uniform read of a small read-only record: the scene tables are never written while a
-// kernel runs, so the kernel reads them through pointers in the constant address space,
-// i.e. with scalar loads into SGPRs (one s_load_dwordx16 for a 64-B record) instead of 64
-// identical vector loads.  The address MUST be the same in every lane.
-template <class T>
-__device__ __forceinline__ T kload(PTX_KPTR(T) p) {
-	T v;
-	__builtin_memcpy(&v, p, sizeof(T));
-	return v;
-}
-
-// ---------------------------------------------------------------------------
-// BVH walk.  The node test is a conservative filter (boxes are padded at build time and
-// the far limit carries a margin above the reference's epsilon), so which leaves get
-// tested never changes the answer: every triangle test is the reference's arithmetic and
-// the winner is min t, ties to the lowest prim id.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void bvh_slab2(float4 q0, float4 q1, float4 q2, f3 inv, f3 noi, float limit, float& tn0, bool& h0,
-                                          float& tn1, bool& h1) {
-	float ax = __builtin_fmaf(q0.x, inv.x, noi.x), bx = __builtin_fmaf(q0.w, inv.x, noi.x);
-	float ay = __builtin_fmaf(q0.y, inv.y, noi.y), by = __builtin_fmaf(q1.x, inv.y, noi.y);
-	float az = __builtin_fmaf(q0.z, inv.z, noi.z), bz = __builtin_fmaf(q1.y, inv.z, noi.z);
-	tn0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-	float tf0 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limit));
-	h0 = tn0 <= tf0;
-	float cx = __builtin_fmaf(q1.z, inv.x, noi.x), dx = __builtin_fmaf(q2.y, inv.x, noi.x);
-	float cy = __builtin_fmaf(q1.w, inv.y, noi.y), dy = __builtin_fmaf(q2.z, inv.y, noi.y);
-	float cz = __builtin_fmaf(q2.x, inv.z, noi.z), dz = __builtin_fmaf(q2.w, inv.z, noi.z);
-	tn1 = fmaxf(fmaxf(fminf(cx, dx), fminf(cy, dy)), fmaxf(fminf(cz, dz), 0.0f));
-	float tf1 = fminf(fminf(fmaxf(cx, dx), fmaxf(cy, dy)), fminf(fmaxf(cz, dz), limit));
-	h1 = tn1 <= tf1;
-}
-
-__device__ __forceinline__ float bvh_rcp(float d) {
-	float r = __builtin_amdgcn_rcpf(d);
-	return fabsf(r) > 1e18f ? copysignf(1e18f, r) : r;
-}
-
-// far limit for node culling given the best reported distance (reported = raw - kEps)
-__device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0f * kEps + 1e-5f * fabsf(best_t)); }
-
-template <bool ANY>
-__device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const float4* __restrict__ tris, int bvh_root, int frame, f3 o, f3 d,
-                                         int* __restrict__ stk, Hit& best, float range) {
-	// Reciprocal direction for the node tests only.  A zero (or denormal-small) component
-	// would give inf and then inf - inf = NaN inside the fused slab test, which fminf/fmaxf
-	// would read as "no constraint on the wrong side"; a huge finite reciprocal keeps the
-	// test ordered, and the padding of the node boxes covers its rounding.
-	f3 inv = {bvh_rcp(d.x), bvh_rcp(d.y), bvh_rcp(d.z)};
-	f3 noi = {-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z)};
-	// Two nested loops instead of one loop that handles "inner node or leaf": a lane descends
-	// through inner nodes until it stands on a leaf and then waits; the triangle tests start
-	// when every lane of the wave stands on a leaf (or has finished).  The wave thus runs the
-	// long triangle code once per round for all its lanes, not once per step of whichever
-	// lane happens to be at a leaf.
-	constexpr int kDone = (int) 0x80000000;  // negative like a leaf reference, never a valid one
-	int sp = 0;
-	int cur = bvh_root;
-	float limit = ANY ? cull_limit(range) : cull_limit(best.t);
-	while (cur != kDone) {
-		while (cur >= 0) {
-			const float4* nd = nodes + (size_t) cur * 4;
-			float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-			float tn0, tn1;
-			bool h0, h1;
-			bvh_slab2(q0, q1, q2, inv, noi, limit, tn0, h0, tn1, h1);
-			int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-			if (h0 && h1) {
-				if (tn1 < tn0) {
-					int tmp = c0;
-					c0 = c1;
-					c1 = tmp;
-				}
-				stk[sp * kBlock] = c1;
-				++sp;
-				cur = c0;
-			} else if (h0) {
-				cur = c0;
-			} else if (h1) {
-				cur = c1;
-			} else if (sp > 0) {
-				--sp;
-				cur = stk[sp * kBlock];
-			} else {
-				cur = kDone;
-			}
-		}
-		if (cur == kDone) break;
-		{
-			int v = ~cur;
-			int first = v >> 3, cnt = (v & 7) + 1;
-			for (int k = 0; k < cnt; ++k) {
-				const float4* tr = tris + (size_t) (first + k) * 3;
-				float4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
-				float t;
-				// most tests end at the first barycentric coordinate: when they do so for the whole wave, skip the rest
-				if (!__ballot(tri_u_ok(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d))) continue;
-				if (tri_t(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, t)) {
-					if (ANY) {
-						if (t <= range) return true;
-					} else {
-						int id = __float_as_int(r2.y);
-						if (t < best.t || (t == best.t && id < best.id)) {
-							best.t = t;
-							best.id = id;
-							best.frame = frame;
-							best.slot = first + k;
-							limit = cull_limit(t);
-						}
-					}
-				}
-			}
-		}
-		if (sp > 0) {
-			--sp;
-			cur = stk[sp * kBlock];
-		} else {
-			cur = kDone;
-		}
-	}
-	return false;
-}
-
-// Per-ray values every test in frame-0 space shares.  They are the same IEEE operations the
-// reference performs inside each Box / Sphere test (1 / d.x ..., normalize(d), length(d)),
-// formed once: a shape whose transform is a pure translation sees the ray's direction
-// unchanged, so its reciprocals, unit vector and length are these very numbers.
-struct RayPre {
-	f3 inv;   // 1.0f / d
-	f3 dn;    // normalize(d)      (only when the scene holds a translated-only sphere)
-	float len;  // length(d)
-	float dd;   // |d|^2, for the bounding-sphere filter only
-};
-__device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 d) {
-	RayPre r;
-	r.dd = __builtin_fmaf(d.x, d.x, __builtin_fmaf(d.y, d.y, d.z * d.z));
-	r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-	r.dn = mk(0, 0, 0);
-	r.len = 0;
-	if (S.has_plain_sphere) {
-		r.dn = normalize(d);
-		r.len = length(d);
-	}
-	return r;
-}
-
-// Conservative filter in front of a leaf's exact test: false only if the ray's line stays
-// outside the leaf's padded bounding sphere, or the ray starts outside it and points away.
-// Like the BVH node test it never produces a value; whatever passes gets the reference's
-// arithmetic.  About a dozen instructions against 45 to 100 for an exact test, and a wave
-// whose 64 rays all fail (the usual case for rays of one pixel) skips the leaf altogether.
-// NaN or infinite intermediate values compare false and so pass.
-__device__ __forceinline__ bool may_hit_sphere(float4 bs, f3 o, f3 d, float dd) {
-	f3 oc = mk(bs.x - o.x, bs.y - o.y, bs.z - o.z);
-	float b = __builtin_fmaf(oc.x, d.x, __builtin_fmaf(oc.y, d.y, oc.z * d.z));
-	float c2 = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, oc.z * oc.z));
-	float lhs = __builtin_fmaf(c2, dd, -(b * b));               // |oc x d|^2, up to rounding of about 1e-7 * c2 * dd
-	float rhs = __builtin_fmaf(c2, 2e-6f, bs.w) * dd;           // (R^2 + slack for that rounding) * |d|^2
-	const bool away = b < 0.0f && c2 > bs.w;
-	return !(lhs > rhs) && !away;
-}
-
-// one leaf of frame 0 against a frame-0-space ray: the reference's per-shape intersect up
-// to the distance.  (1*x + 0*y) + (0*z + t*1) == x + t for finite operands, so a
-// translated-only shape gets its local origin with one addition per component.
-__device__ __forceinline__ bool root_prim_t(const DevScene& S, const DevRootPrim& P, f3 o, f3 d, const RayPre& pre, float& t) {
-	const int kind = P.kind_flags & 0xff;
-	if (P.kind_flags & kPlain) {
-		f3 lo = o + ld3(P.tinv);
-		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
-		if (kind == PTX_BOX) return box_slab_inv(ld3(P.p), ld3(P.p + 3), lo, d, pre.inv, t);
-		return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, d, t);
-	}
-	const Mat16 Wi = kload(reinterpret_cast<PTX_KPTR(Mat16)>(S.xforms_k + P.xform));
-	f3 lo = xform_point(Wi.m, o), ld = xform_dir(Wi.m, d);
-	if (kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
-	if (kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
-	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
-}
-
-__device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, int f, f3 o, f3 d, f3& lo, f3& ld) {
-	if (F.plain) {
-		lo = o + ld3(F.tinv);
-		ld = d;
-	} else {
-		const Mat16 Wi = kload(S.frame_winv_k + f);
-		lo = xform_point(Wi.m, o);
-		ld = xform_dir(Wi.m, d);
-	}
-}
-
-// scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103.
-// In parts, so that the closest-hit kernel can run the mesh walks of several steps together
-// (see k_trace):
-//   closest_root    root bounds + the leaves of frame 0; false when the ray misses the root bounds
-//   frame_mask      bit f set: the ray enters the bounds of mesh frame f (frames 1..31; bit 0
-//                   set: there are frames beyond 31, which closest_frames tests itself)
-//   closest_frames  the mesh frames; with `known` a frame below 32 is walked iff its bit is set
-__device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, const RayPre& pre, Hit& best) {
-	best.t = kInf;
-	best.id = -1;
-	best.frame = 0;
-	best.slot = 0;
-	float unused;
-	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return false;
-	for (int i = 0; i < S.n_root_prims; ++i) {
-		if (!__ballot(may_hit_sphere(kload(S.root_bound_k + i), o, d, pre.dd))) continue;
-		const DevRootPrim P = kload(S.root_prims_k + i);
-		float t;
-		const bool hit = root_prim_t(S, P, o, d, pre, t);
-		const bool better = hit && (t < best.t || (t == best.t && P.id < best.id));
-		best.t = better ? t : best.t;
-		best.id = better ? P.id : best.id;
-		best.slot = better ? i : best.slot;
-	}
-	return true;
-}
-__device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, const RayPre& pre) {
-	unsigned mask = S.n_frames > 32 ? 1u : 0u;
-	float unused;
-	const int nf = S.n_frames < 32 ? S.n_frames : 32;
-	for (int f = 1; f < nf; ++f) {
-		const DevFrame F = kload(S.frames_k + f);
-		if (!F.has_prims) continue;
-		if (box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) mask |= 1u << f;
-	}
-	return mask;
-}
-template <bool KNOWN>
-__device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, const RayPre& pre, unsigned known, int* __restrict__ stk, Hit& best) {
-	float unused;
-	for (int f = 1; f < S.n_frames; ++f) {
-		const DevFrame F = kload(S.frames_k + f);
-		if (!F.has_prims) continue;
-		if (KNOWN && f < 32) {
-			if (!(known >> f & 1u)) continue;
-		} else if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
-		f3 lo, ld;
-		frame_ray(S, F, f, o, d, lo, ld);
-		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f);
-	}
-}
-__device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
-	const RayPre pre = ray_pre(S, d);
-	if (!closest_root(S, o, d, pre, best)) return;
-	closest_frames<false>(S, o, d, pre, 0u, stk, best);
-}
-
-// find_light_block(...).does_intersect, framework/renderer.cpp:168-175: the closest hit
-// lies within `range`  <=>  some leaf is hit at distance <= range.
-__device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
-	float t;
-	RayPre pre = ray_pre(S, d);
-	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, t)) return false;
-	for (int i = 0; i < S.n_root_prims; ++i) {
-		if (!__ballot(may_hit_sphere(kload(S.root_bound_k + i), o, d, pre.dd))) continue;
-		const DevRootPrim P = kload(S.root_prims_k + i);
-		if (root_prim_t(S, P, o, d, pre, t) && t <= range) return true;
-	}
-	Hit dummy;
-	for (int f = 1; f < S.n_frames; ++f) {
-		const DevFrame F = kload(S.frames_k + f);
-		if (!F.has_prims) continue;
-		if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, t)) continue;
-		f3 lo, ld;
-		frame_ray(S, F, f, o, d, lo, ld);
-		if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range)) return true;
-	}
-	return false;
-}
-
-struct Surface {  // the HitPoint fields shading reads, framework/hitPoint.hpp:8-16
-	f3 pos, n, rdir;
-};
-
-// Rebuilds position / normal / ray_direction of the winning leaf exactly as the leaf and
-// the Composites above it would have produced them.
-__device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
-	Surface s;
-	if (h.frame == 0) {
-		const DevRootPrim& P = S.root_prims[h.slot];
-		const DevRootShade& Q = S.root_shade[h.slot];
-		const int kind = P.kind_flags & 0xff;
-		// the shape's real matrices, also for translated-only shapes: the zeros of an inverted
-		// translation carry signs, and the sign of a zero normal component follows them
-		const DevXform& X = S.xforms[h.slot];  // one per root leaf, in the same order
-		f3 lo = xform_point(X.winv, o), ld = xform_dir(X.winv, d);
-		if (kind == PTX_TRIANGLE) {  // framework/triangle.cpp:86
-			s.pos = o + d * h.t;
-			s.rdir = ld;
-			s.n = ld3(Q.n);  // constant per triangle: transformed and re-normalised at upload
-		} else {
-			if (kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
-				s.pos = xform_point(X.w, lo + ld * h.t);
-				s.n = normalize(s.pos - xform_point(X.w, ld3(P.p)));
-			} else {  // framework/box.cpp:98-100
-				f3 nl = box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t);
-				s.n = normalize(xform_dir(X.w, nl));
-				s.pos = o + d * h.t;
-			}
-			s.rdir = d;
-			for (int k = 0; k < Q.levels_in; ++k) s.n = normalize(s.n);  // identity-transform Composites up to the root
-		}
-	} else {
-		const float* Fwinv = S.frame_winv[h.frame].m;  // h.frame differs between lanes: ordinary loads
-		const float* Fw = S.frame_w[h.frame].m;
-		f3 lo = xform_point(Fwinv, o), ld = xform_dir(Fwinv, d);
-		float4 info = S.prim_info[h.id];
-		s.n = mk(info.x, info.y, info.z);  // constant per triangle: the whole chain of Composites applied at upload
-		s.pos = xform_point(Fw, lo + ld * h.t);
-		s.rdir = ld;  // stays in mesh-local space: Composite never maps ray_direction back
-	}
-	return s;
-}
-
-struct Material {
-	f3 ka, kd, ks;
-	float m, glossy, opacity, ior;
-};
-__device__ __forceinline__ Material load_material(const DevScene& S, int prim_id) {
-	const float4* p = S.materials + (size_t) prim_id * 4;
-	float4 a = p[0], b = p[1], c = p[2], e = p[3];
-	return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, c.y, c.z, c.w, e.x};
-}
-
-// One light's term of Renderer::phong_color (framework/renderer.cpp:142-163) without the
-// shadow test: direction and distance to the light, diffuse + specular (:177-192; pow is the
-// double overload there).  Returns false when the term adds nothing (back-facing, or
-// exactly zero), in which case the reference's shadow query cannot change the result.
-struct LightTerm {
-	f3 ldir, diffuse, spec;
-	float dist;
-	bool has_spec;
-};
-// (float) pow((double) x, (double) m) for a material exponent that is a whole number in
-// [1, kIntPowMax]: square-and-multiply in double.  Every product is rounded once, so the
-// result is within about m * 2^-54 of the true power, far inside what survives the final
-// rounding to float (the general pow of the device library is as accurate but keeps some
-// forty more registers live, which costs the shading kernels a wave per SIMD).  x >= 0, or
-// NaN, which the products pass on like pow does.
-constexpr float kIntPowMax = 4095.0f;
-__device__ __forceinline__ float pow_int(float x, float m) {
-	double b = (double) x, r = 1.0;
-	unsigned e = (unsigned) m;
-	while (__ballot(e != 0)) {
-		if (e & 1u) r *= b;
-		b *= b;
-		e >>= 1;
-	}
-	return (float) r;
-}
-
-template <bool INTPOW>
-__device__ __forceinline__ bool light_term(const DevScene& S, int l, const Surface& sf, f3 kd, f3 ks, float m, LightTerm& T) {
-	const float4 lp = kload(S.lights_k + 2 * l), li = kload(S.lights_k + 2 * l + 1);
-	f3 ldir = mk(lp.x, lp.y, lp.z) - sf.pos;
-	T.dist = length(ldir);
-	ldir = normalize(ldir);
-	T.ldir = ldir;
-	float c = dot(sf.n, ldir);
-	f3 I = {li.x, li.y, li.z};
-	T.diffuse = cmul(I, kd) * c;
-	T.spec = mk(0, 0, 0);
-	T.has_spec = (m != 0.0f);
-	if (m != 0.0f && !(c < 0.0f)) {
-		f3 r = 2 * dot(sf.n, ldir) * sf.n - ldir;
-		float cs = dot(r, sf.rdir * -1.0f);
-		if (!(cs < 0.0f)) {
-			float f = INTPOW ? pow_int(cs, m) : (float) pow((double) cs, (double) m);
-			T.spec = cmul(I, ks) * f;
-		}
-	}
-	if (c < 0.0f) return false;
-	return any_nonzero(T.diffuse) || any_nonzero(T.spec);
-}
-
-// Renderer::phong_color with the shadow walk inline (fused pipeline)
-template <bool INTPOW>
-__device__ __forceinline__ f3 phong(const DevScene& S, const Surface& sf, const Material& M, int* __restrict__ stk, unsigned& n_shadow) {
-	f3 col = cmul(ld3(S.ambient), M.ka);
-	for (int l = 0; l < S.n_lights; ++l) {
-		LightTerm T;
-		if (!light_term<INTPOW>(S, l, sf, M.kd, M.ks, M.m, T)) continue;
-		++n_shadow;
-		if (trace_any(S, sf.pos, T.ldir, T.dist, stk)) continue;
-		col = col + T.diffuse;
-		if (T.has_spec) col = col + T.spec;
-	}
-	return col;
-}
-
-struct Child {
-	f3 o, d, w;
-	bool live;
-};
-
-// The part of Renderer::shade after the Phong term (framework/renderer.cpp:117-134) with
-// reflection (:194-201) and refraction (:203-225) turned into weighted child rays: the
-// child's colour enters the parent linearly, so weight_child = weight * (factor the
-// reference multiplies it by).  k1 is the factor the reference applies to the local colour
-// after `phong * opacity` (1 when no case applies).
-__device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& M, f3 weight, bool last_depth, Child& refl, Child& refr,
-                                             float& k1) {
-	refl.live = false;
-	refr.live = false;
-	k1 = 1.0f;
-	if (last_depth) return;
-
-	float w_refl = 0.0f, w_refr = 0.0f;  // scalar factors on reflection()*ks and refraction()*kd
-	bool want_refl = false, want_refr = false;
-	if (M.glossy > 0.0f && M.opacity < 1.0f) {
-		float R = schlick(sf.rdir, sf.n, M.ior);
-		k1 = R * M.opacity;
-		w_refl = R;
-		w_refr = (1.0f - R) * (1.0f - M.opacity);
-		want_refl = want_refr = true;
-	} else if (M.glossy > 0.0f) {
-		float R = schlick(sf.rdir, sf.n, M.ior);
-		R = M.glossy + (1.0f - M.glossy) * R;
-		k1 = 1.0f - R;
-		w_refl = R;
-		want_refl = true;
-	} else if (M.opacity < 1.0f) {
-		k1 = M.opacity;
-		w_refr = 1.0f - M.opacity;
-		want_refr = true;
-	}
-	f3 wr = {0, 0, 0};  // total weight on the reflection ray
-	if (want_refl) wr = cmul(weight, M.ks) * w_refl;
-	if (want_refr) {
-		f3 rd = sf.rdir, n = sf.n;
-		float eta = 1.0f / M.ior;
-		float ci = -dot(n, rd);
-		if (ci < 0.0f) {
-			eta = 1.0f / eta;
-			ci *= -1.0f;
-			n = n * -1.0f;
-		}
-		float k = 1.0f - eta * eta * (1.0f - ci * ci);
-		if (k < 0.0f) {
-			// total internal reflection: refraction() returns reflection() (same ray, tinted by ks)
-			f3 extra = cmul(weight, M.ks);
-			if (M.glossy > 0.0f) extra = (extra * (1.0f - w_refl)) * (1.0f - M.opacity);
-			else extra = extra * w_refr;
-			wr = wr + extra;
-			want_refl = true;
-		} else {
-			f3 wt = cmul(weight, M.kd);
-			if (M.glossy > 0.0f) wt = (wt * (1.0f - w_refl)) * (1.0f - M.opacity);
-			else wt = wt * w_refr;
-			if (any_nonzero(wt)) {
-				refr.o = sf.pos - n * (2 * kEps);
-				refr.d = rd * eta + n * (eta * ci - __builtin_sqrtf(k));
-				refr.w = wt;
-				refr.live = true;
-			}
-		}
-	}
-	if (want_refl && any_nonzero(wr)) {
-		float ci = -dot(sf.n, sf.rdir);
-		refl.o = sf.pos;
-		refl.d = sf.rdir + (sf.n * ci * 2.0f);
-		refl.w = wr;
-		refl.live = true;
-	}
-}
-
-// Renderer::shade for the fused pipeline: weight * (phong * opacity * k1), children out
-template <bool INTPOW>
-__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, int prim_id, f3 weight, bool last_depth, int* __restrict__ stk,
-                                    Child& refl, Child& refr, unsigned& n_shadow) {
-	Material M = load_material(S, prim_id);
-	f3 c = phong<INTPOW>(S, sf, M, stk, n_shadow) * M.opacity;
-	float k1;
-	bounce_terms(sf, M, weight, last_depth, refl, refr, k1);
-	c = c * k1;
-	return cmul(weight, c);
-}
-
-// ---------------------------------------------------------------------------
-// wave64 helpers
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ unsigned long long lanes_below(unsigned lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
-
-// Adds `v` of the lanes with `has` into accum[pix*3..]: the wave is cut into runs of
-// consecutive lanes with equal pixel (rays stay in pixel order through compaction), each
-// run is summed with shuffles and its first lane issues the three atomics.
-__device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned pix, f3 v, bool has) {
-	if (__ballot(has) == 0) return;
-	unsigned lane = lane_id();
-	if (!has) v = mk(0, 0, 0);
-	unsigned up = __shfl_up(pix, 1);
-	bool head = lane == 0 || up != pix;
-	unsigned long long heads = __ballot(head);
-	unsigned seg = __builtin_popcountll(heads & (lanes_below(lane) | (1ull << lane)));  // run number, non-decreasing
-	int any = has ? 1 : 0;
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		float ox = __shfl_down(v.x, off), oy = __shfl_down(v.y, off), oz = __shfl_down(v.z, off);
-		unsigned os = __shfl_down(seg, off);
-		int oa = __shfl_down(any, off);
-		if (lane + off < 64 && os == seg) {
-			v.x += ox;
-			v.y += oy;
-			v.z += oz;
-			any |= oa;
-		}
-	}
-	if (head && any) {
-		float* p = accum + (size_t) pix * 3;
-		atomicAdd(p, v.x);
-		atomicAdd(p + 1, v.y);
-		atomicAdd(p + 2, v.z);
-	}
-}
-
-// u / n and u % n for u < 2^31 with inv = 1.0 / n in double: the product is below the true
-// quotient by less than one, so truncating it gives the quotient or one less, which the
-// remainder shows.  (A handful of instructions; the compiler's 32-bit division takes about
-// 25 and the 64-bit one well over a hundred, per ray.)
-__device__ __forceinline__ void udivmod(unsigned u, unsigned n, double inv, unsigned& q, unsigned& r) {
-	q = (unsigned) ((double) u * inv);
-	r = u - q * n;
-	if (r >= n) {
-		++q;
-		r -= n;
-	}
-}
-
-__device__ __forceinline__ void make_primary(const DevCamera& cam, unsigned pixel, unsigned s, f3& o, f3& d) {
-	// framework/renderer.cpp:66-67, :76-82
-	unsigned x, y, ax, ay;
-	udivmod(pixel, cam.width, cam.inv_width, y, x);
-	udivmod(s, cam.aa_steps, cam.inv_aa, ax, ay);
-	int aax = (int) ax, aay = (int) ay;
-	f3 pp = {x + aax * cam.aa_unit - cam.half_w, y + aay * cam.aa_unit - cam.half_h, -cam.dist};
-	if (cam.jitter_seed) {  // jittered sampling (not in the reference): a point inside the sample's cell
-		float jx, jy;
-		jitter_offsets(cam.jitter_seed, pixel, s, jx, jy);
-		pp.x = x + (aax + jx) * cam.aa_unit - cam.half_w;
-		pp.y = y + (aay + jy) * cam.aa_unit - cam.half_h;
-	}
-	f3 n = normalize(pp);
-	d = xform_dir(cam.m, n);
-	o = mk(cam.m[12], cam.m[13], cam.m[14]);
-}
-
-// ---------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------
-struct BounceArgs {
-	DevScene S;
-	DevCamera cam;
-	RayQueue in, out;
-	const unsigned* in_count;  // kNQ tail counters of `in` (depth > 0), kCountPad words apart
-	unsigned* out_count;       // kNQ tail counters of `out`
-	unsigned out_subcap;       // slots per sub-queue of `out`
-	unsigned in_subcap;
-	unsigned in_offset;        // first ray (in the concatenation of the sub-queues) this launch takes
-	unsigned in_take;          // rays this launch takes from in_offset on; 0 = all of them
-	unsigned first_pix, first_s;  // depth 0: the batch starts at sample first_s (< ns) of this render's range in pixel first_pix
-	double inv_ns;             // 1.0 / ns
-	unsigned batch;            // depth 0: samples in the batch; depth > 0 with in_count == NULL: rays to take
-	unsigned ns, s0;           // samples per pixel in this render's range, first sample
-	unsigned depth;
-	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
-	float* accum;
-	Counters* counters;        // overflow flag only
-	unsigned long long* stat;  // per-wave work counters
-	// staged pipeline only
-	RayQueue shadow;           // a = (o.xyz, bits(pixel))  b = (contribution rgb, bits(light)); plane c unused (32 B per shadow ray)
-	unsigned* shadow_count;    // kNQ tail counters of `shadow`
-	unsigned shadow_subcap;
-	float4* hits;              // hit list of the launch, sub-queued like the ray queues: (t, bits(prim id), bits(where), bits(ray index))
-	unsigned* hit_count;       // kNQ tail counters of `hits`
-	unsigned hit_subcap;
-};
-
-// Records held by a sub-queued queue: fills pfx (in LDS) with the first record index of every
-// sub-queue in their concatenation and returns how many of the records from `offset` on the
-// launch takes (`take` = 0: all of them).  All threads of the workgroup must call it.
-__device__ __forceinline__ unsigned queue_input(const unsigned* count, unsigned subcap, unsigned* pfx, unsigned offset, unsigned take) {
-	const unsigned lane = lane_id();
-	if (threadIdx.x < 64) {
-		unsigned c = min(count[threadIdx.x * kCountPad], subcap);
-		for (int off = 1; off < 64; off <<= 1) {
-			unsigned t = __shfl_up(c, off);
-			if (lane >= (unsigned) off) c += t;
-		}
-		pfx[lane + 1] = c;
-		if (lane == 0) pfx[0] = 0;
-	}
-	__syncthreads();
-	const unsigned total_in = pfx[kNQ];
-	const unsigned avail = total_in > offset ? total_in - offset : 0;
-	return take ? min(take, avail) : avail;
-}
-// number of input rays of a launch: the primary batch, or what the launch takes of queue `in`
-template <bool PRIMARY>
-__device__ __forceinline__ unsigned launch_input(const BounceArgs& A, unsigned* pfx) {
-	if (PRIMARY) return A.batch;
-	return queue_input(A.in_count, A.in_subcap, pfx, A.in_offset, A.in_take);
-}
-
-// ray index of the launch -> record index in a sub-queued queue (binary search over pfx)
-__device__ __forceinline__ size_t queue_slot(const unsigned* pfx, unsigned subcap, unsigned g) {
-	unsigned lo_q = 0, hi_q = kNQ;
-#pragma unroll
-	for (int it = 0; it < 6; ++it) {
-		unsigned mid = (lo_q + hi_q) >> 1;
-		bool ge = pfx[mid] <= g;
-		lo_q = ge ? mid : lo_q;
-		hi_q = ge ? hi_q : mid;
-	}
-	return (size_t) lo_q * subcap + (g - pfx[lo_q]);
-}
-
-// the i-th input ray of a launch: generated (depth 0, framework/renderer.cpp:76-82) or read from `in`
-template <bool PRIMARY>
-__device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* pfx, unsigned i, f3& o, f3& d, f3& w, unsigned& pix) {
-	if (PRIMARY) {
-		unsigned dp, s;
-		udivmod(A.first_s + i, A.ns, A.inv_ns, dp, s);
-		pix = A.first_pix + dp;
-		s += A.s0;
-		make_primary(A.cam, pix, s, o, d);
-		w = mk(1, 1, 1);
-	} else {
-		const size_t j = queue_slot(pfx, A.in_subcap, A.in_offset + i);
-		const float4 a = A.in.a[j], b = A.in.b[j];
-		const float2 c = A.in.c[j];
-		o = mk(a.x, a.y, a.z);
-		d = mk(a.w, b.x, b.y);
-		w = mk(b.z, b.w, c.x);
-		pix = __float_as_uint(c.y);
-	}
-}
-
-// Sub-queue that takes the records a wave emits for the step starting at ray `base` of a
-// launch: the steps go round the sub-queues.
-__device__ __forceinline__ unsigned sub_queue_of(unsigned long long base) { return (unsigned) (base >> 6) & (kNQ - 1); }
-
-// wave64 ballot compaction of up to two records per lane into sub-queue q of a queue: the
-// records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.  The
-// two halves are separate calls so that a kernel can put independent work between asking
-// for the slots and needing them (the atomic's round trip to the memory side is long).
-struct Reserved {
-	unsigned slot0;  // lane 0 only until emit_write broadcasts it
-	unsigned q;
-	unsigned long long m1, m2;
-};
-__device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned long long base, bool live1, bool live2) {
-	Reserved R;
-	R.m1 = __ballot(live1);
-	R.m2 = __ballot(live2);
-	R.slot0 = 0;
-	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
-	R.q = sub_queue_of(base);
-	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + R.q * kCountPad, total);
-	return R;
-}
-template <bool WITH_C = true>
-__device__ __forceinline__ void emit_write(const RayQueue& Q, unsigned subcap, const Reserved& R, bool live1, const float4 r1[3],
-                                           bool live2, const float4 r2[3], Counters* counters) {
-	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
-	if (!total) return;
-	const unsigned lane = lane_id();
-	const unsigned q = R.q;
-	const unsigned slot0 = __shfl(R.slot0, 0);
-	unsigned long long lt = lanes_below(lane);
-	unsigned my = slot0 + __builtin_popcountll(R.m1 & lt) + __builtin_popcountll(R.m2 & lt);
-	const size_t qbase = (size_t) q * subcap;
-	if (live1) {
-		if (my < subcap) {
-			Q.a[qbase + my] = r1[0];
-			Q.b[qbase + my] = r1[1];
-			if (WITH_C) Q.c[qbase + my] = make_float2(r1[2].x, r1[2].y);
-		}
-		++my;
-	}
-	if (live2 && my < subcap) {
-		Q.a[qbase + my] = r2[0];
-		Q.b[qbase + my] = r2[1];
-		if (WITH_C) Q.c[qbase + my] = make_float2(r2[2].x, r2[2].y);
-	}
-	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);
-}
-__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned long long base, bool live1,
-                                          const float4 r1[3], bool live2, const float4 r2[3], Counters* counters) {
-	const Reserved R = emit_reserve(tails, base, live1, live2);
-	emit_write(Q, subcap, R, live1, r1, live2, r2, counters);
-}
-
-__device__ __forceinline__ void pack_child(const Child& c, unsigned pix, float4 r[3]) {
-	r[0] = make_float4(c.o.x, c.o.y, c.o.z, c.d.x);
-	r[1] = make_float4(c.d.y, c.d.z, c.w.x, c.w.y);
-	r[2] = make_float4(c.w.z, __uint_as_float(pix), 0.f, 0.f);
-}
-
-__device__ __forceinline__ void wave_stats(const BounceArgs& A, unsigned wave, unsigned trace, unsigned shadow, unsigned hits) {
-	for (int off = 32; off > 0; off >>= 1) {
-		trace += __shfl_down(trace, off);
-		shadow += __shfl_down(shadow, off);
-		hits += __shfl_down(hits, off);
-	}
-	if (lane_id() == 0 && (trace | shadow | hits)) {
-		unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
-		unsigned long long* st = A.stat + ((size_t) slot * kStatWaves + (wave % kStatWaves)) * 4;
-		if (wave < kStatWaves) {
-			st[0] += trace;
-			st[1] += shadow;
-			st[2] += hits;
-		} else {  // more waves than slots (cannot happen with the grids this file launches)
-			atomicAdd(st, (unsigned long long) trace);
-			atomicAdd(st + 1, (unsigned long long) shadow);
-			atomicAdd(st + 2, (unsigned long long) hits);
-		}
-	}
-}
-
-// ---- fused pipeline: one kernel per depth -----------------------------------------------
-template <bool PRIMARY, bool INTPOW>
-__global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
-	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned pfx[kNQ + 1];
-	int* stk = lds_stack + threadIdx.x;
-	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, pfx);
-	const unsigned waves_per_block = kBlock / 64;
-	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * waves_per_block;
-	unsigned cnt_trace = 0, cnt_shadow = 0, cnt_hits = 0;
-
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
-		bool active = i < n;
-		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
-		unsigned pix = 0;
-		if (active) input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
-		Hit h;
-		h.id = -1;
-		if (active) {
-			trace_closest(A.S, o, d, stk, h);
-			++cnt_trace;
-		}
-		bool hit = active && h.id >= 0;
-		f3 contrib = {0, 0, 0};
-		Child refl, refr;
-		refl.live = refr.live = false;
-		if (hit) {
-			Surface sf = surface_of(A.S, o, d, h);
-			contrib = shade<INTPOW>(A.S, sf, h.id, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
-			++cnt_hits;
-		}
-		accumulate(A.accum, pix, contrib, hit);
-		float4 r1[3], r2[3];
-		pack_child(refl, pix, r1);
-		pack_child(refr, pix, r2);
-		emit_pair(A.out, A.out_count, A.out_subcap, base, refl.live, r1, refr.live, r2, A.counters);
-	}
-	wave_stats(A, wave, cnt_trace, cnt_shadow, cnt_hits);
-}
-
-// ---- staged pipeline: closest hit / shading / shadow rays as three lean kernels ---------
-// k_trace needs no shading state and k_shade no traversal state, so each fits twice the
-// waves per SIMD of the fused kernel.  k_trace leaves a compacted list of 16-byte hit
-// records (most primary rays of a typical frame hit nothing), so k_shade runs full waves of
-// hits only and fetches (or, at depth 0, regenerates) just the rays that hit.
-// Only some of a step's 64 rays get as far as a mesh; the others are settled by the leaves of
-// frame 0 or miss every mesh's bounds.  Walking a BVH with the few that remain leaves most
-// lanes idle (measured: 13 of 64 on the incoherent depths), so unless most of the step goes
-// on (kWalkNow lanes) the wave parks those rays - ray index and the best hit so far - in a
-// small ring in LDS and walks once 64 of them have gathered, with every lane busy at the start.
-constexpr unsigned kRing = 128;    // parked rays per wave
-constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
-template <bool PRIMARY>
-__global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
-	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned pfx[kNQ + 1];
-	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
-	int* stk = lds_stack + threadIdx.x;
-	volatile float4* ring = ring_mem + (threadIdx.x >> 6) * kRing;
-	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, pfx);
-	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * (kBlock / 64);
-	unsigned cnt_trace = 0;
-	unsigned parked = 0, emits = wave;  // the same in every lane
-	// the hit records of the lanes with `hit`, compacted, into one sub-list (keeping them in
-	// registers until the atomic's answer has arrived, a step later, was measured: no gain)
-	auto emit = [&](bool hit, const Hit& h, unsigned i) {
-		const unsigned long long m = __ballot(hit);
-		if (!m) return;
-		const unsigned total = __builtin_popcountll(m);
-		const unsigned q = sub_queue_of((unsigned long long) emits++ << 6);
-		unsigned slot0 = 0;
-		if (lane == 0) slot0 = atomicAdd(A.hit_count + q * kCountPad, total);
-		slot0 = __shfl(slot0, 0);
-		const unsigned my = slot0 + __builtin_popcountll(m & lanes_below(lane));
-		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
-		const int where = h.frame == 0 ? h.slot : -h.frame;
-		if (hit && my < A.hit_subcap)
-			A.hits[(size_t) q * A.hit_subcap + my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(i));
-		if (lane == 0 && slot0 + total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);
-	};
-	// the mesh walks of the `count` most recently parked rays
-	auto walk_parked = [&](unsigned count) {
-		Hit h;
-		h.id = -1;
-		h.frame = 0;
-		h.slot = 0;
-		h.t = kInf;
-		unsigned i = 0;
-		if (lane < count) {
-			const volatile float4* rq = ring + (parked - count + lane);
-			h.t = rq->x;
-			h.id = __float_as_int(rq->y);
-			h.slot = __float_as_int(rq->z);
-			i = __float_as_uint(rq->w);
-			f3 o, d, w;
-			unsigned pix;
-			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
-			const RayPre pre = ray_pre(A.S, d);
-			closest_frames<false>(A.S, o, d, pre, 0u, stk, h);
-		}
-		parked -= count;
-		emit(h.id >= 0, h, i);
-	};
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
-		Hit h;
-		h.id = -1;
-		h.frame = 0;
-		h.slot = 0;
-		h.t = kInf;
-		f3 o = {0, 0, 0}, d = {0, 0, 1}, w;
-		unsigned pix, frames = 0;
-		RayPre pre = ray_pre(A.S, d);
-		if (i < n) {
-			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
-			pre = ray_pre(A.S, d);
-			if (closest_root(A.S, o, d, pre, h)) frames = frame_mask(A.S, o, d, pre);
-			++cnt_trace;
-		}
-		bool park = frames != 0;
-		const unsigned long long m = __ballot(park);
-		const unsigned cnt = __builtin_popcountll(m);
-		// most of the wave goes on to a mesh (or these are primary rays, neighbours in the image):
-		// walk here, the rays are in registers
-		const bool walk_now = PRIMARY || cnt >= kWalkNow;
-		if (walk_now) {
-			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h);
-			park = false;
-		}
-		emit(h.id >= 0 && !park, h, i);
-		if (cnt && !walk_now) {
-			if (parked + cnt > kRing) walk_parked(parked < 64 ? parked : 64);
-			if (park) {
-				volatile float4* rq = ring + (parked + __builtin_popcountll(m & lanes_below(lane)));
-				rq->x = h.t;
-				rq->y = __int_as_float(h.id);
-				rq->z = __int_as_float(h.slot);
-				rq->w = __uint_as_float(i);
-			}
-			parked += cnt;
-			if (parked >= 64) walk_parked(64);
-		}
-	}
-	if (parked) walk_parked(parked);
-	wave_stats(A, wave, cnt_trace, 0, 0);
-}
-
-template <bool PRIMARY, bool INTPOW>
-__global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) {
-	__shared__ unsigned pfx_hit[kNQ + 1];
-	__shared__ unsigned pfx[kNQ + 1];
-	const unsigned n = queue_input(A.hit_count, A.hit_subcap, pfx_hit, 0, 0);
-	if (!PRIMARY) (void) launch_input<false>(A, pfx);
-	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * (kBlock / 64);
-	unsigned cnt_shadow = 0, cnt_hits = 0;
-	// the hit record of a step is fetched one step ahead, so that its trip from memory runs
-	// beside the previous step's work instead of in front of this step's
-	const unsigned long long stride = (unsigned long long) n_waves * 64;
-	auto fetch_hit = [&](unsigned long long b) {
-		const unsigned j = (unsigned) b + lane_id();
-		return j < n ? A.hits[queue_slot(pfx_hit, A.hit_subcap, j)] : make_float4(0.f, 0.f, 0.f, 0.f);
-	};
-	unsigned long long base = (unsigned long long) wave * 64;
-	float4 hr_next = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (base < n) hr_next = fetch_hit(base);
-	for (; base < n; base += stride) {
-		const unsigned i = (unsigned) base + lane_id();
-		const bool hit = i < n;
-		const float4 hr = hr_next;
-		if (base + stride < n) hr_next = fetch_hit(base + stride);
-		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
-		unsigned pix = 0;
-		Surface sf;
-		sf.pos = sf.n = sf.rdir = mk(0, 0, 0);
-		f3 kd = {0, 0, 0}, ks = {0, 0, 0}, ws = {0, 0, 0};
-		float mm = 0.0f, scale0 = 0.0f, k1 = 1.0f;
-		f3 contrib = {0, 0, 0};
-		Child refl, refr;
-		refl.live = refr.live = false;
-		if (hit) {
-			Hit h;
-			h.t = hr.x;
-			h.id = __float_as_int(hr.y);
-			const int where = __float_as_int(hr.z);
-			h.frame = where < 0 ? -where : 0;
-			h.slot = where < 0 ? 0 : where;
-			input_ray<PRIMARY>(A, pfx, __float_as_uint(hr.w), o, d, w, pix);
-			sf = surface_of(A.S, o, d, h);
-			Material M = load_material(A.S, h.id);
-			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
-			kd = M.kd;
-			ks = M.ks;
-			mm = M.m;
-			scale0 = M.opacity;
-			ws = w;
-			// ambient part of phong_color (renderer.cpp:140), scaled like the whole local colour
-			contrib = cmul(w, (cmul(ld3(A.S.ambient), M.ka) * M.opacity) * k1);
-			++cnt_hits;
-		}
-		// the slots of the child rays are asked for first and used last: the light terms, the
-		// shadow records and the accumulation all fit inside that atomic's round trip
-		const Reserved rc = emit_reserve(A.out_count, base, refl.live, refr.live);
-		bool accumulated = false;
-		// one shadow ray per light whose term can add something; its record carries the finished
-		// contribution weight * ((diffuse + specular) * opacity * k1)
-		for (int l = 0; l < A.S.n_lights; ++l) {
-			bool want = false;
-			float4 r[3];
-			if (hit) {
-				LightTerm T;
-				want = light_term<INTPOW>(A.S, l, sf, kd, ks, mm, T);
-				f3 term = T.diffuse;
-				if (T.has_spec) term = term + T.spec;
-				f3 c = cmul(ws, (term * scale0) * k1);
-				// (k_shadow forms the direction and distance to the light again, with the same operations)
-				r[0] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(pix));
-				r[1] = make_float4(c.x, c.y, c.z, __int_as_float(l));
-				r[2] = r[1];
-			}
-			if (want) ++cnt_shadow;
-			const Reserved rs = emit_reserve(A.shadow_count, base, want, false);
-			if (!accumulated) accumulate(A.accum, pix, contrib, hit);
-			accumulated = true;
-			emit_write<false>(A.shadow, A.shadow_subcap, rs, want, r, false, r, A.counters);
-		}
-		if (!accumulated) accumulate(A.accum, pix, contrib, hit);
-		float4 r1[3], r2[3];
-		pack_child(refl, pix, r1);
-		pack_child(refr, pix, r2);
-		emit_write(A.out, A.out_subcap, rc, refl.live, r1, refr.live, r2, A.counters);
-	}
-	wave_stats(A, wave, 0, cnt_shadow, cnt_hits);
-}
-
-// find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
-// unblocked ray adds its contribution to its pixel
-__global__ __launch_bounds__(kBlock) void k_shadow(BounceArgs A) {
-	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned pfx[kNQ + 1];
-	int* stk = lds_stack + threadIdx.x;
-	const unsigned lane = lane_id();
-	const unsigned n = queue_input(A.shadow_count, A.shadow_subcap, pfx, 0, 0);
-	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * (kBlock / 64);
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
-		bool active = i < n;
-		unsigned pix = 0;
-		f3 c = {0, 0, 0};
-		bool lit = false;
-		if (active) {
-			const size_t j = queue_slot(pfx, A.shadow_subcap, i);
-			const float4 a = A.shadow.a[j], b = A.shadow.b[j];
-			pix = __float_as_uint(a.w);
-			c = mk(b.x, b.y, b.z);
-			// direction and distance to the light exactly as light_term formed them (renderer.cpp:144-147)
-			const float4 lp = A.S.lights[2 * __float_as_int(b.w)];
-			const f3 pos = mk(a.x, a.y, a.z);
-			f3 ldir = mk(lp.x, lp.y, lp.z) - pos;
-			const float dist = length(ldir);
-			ldir = normalize(ldir);
-			lit = !trace_any(A.S, pos, ldir, dist, stk);
-		}
-		accumulate(A.accum, pix, c, lit);
-	}
-}
-
-// sums the per-wave statistic words into the compact block the host reads
-__global__ __launch_bounds__(kBlock) void k_stats_reduce(const unsigned long long* __restrict__ stat, Counters* __restrict__ out) {
-	__shared__ unsigned long long red[kBlock * 3];
-	const unsigned depth = blockIdx.x;
-	unsigned long long a = 0, b = 0, c = 0;
-	for (unsigned w = threadIdx.x; w < kStatWaves; w += kBlock) {
-		const unsigned long long* st = stat + ((size_t) depth * kStatWaves + w) * 4;
-		a += st[0];
-		b += st[1];
-		c += st[2];
-	}
-	red[threadIdx.x] = a;
-	red[kBlock + threadIdx.x] = b;
-	red[2 * kBlock + threadIdx.x] = c;
-	__syncthreads();
-	for (unsigned s = kBlock / 2; s > 0; s >>= 1) {
-		if (threadIdx.x < s) {
-			red[threadIdx.x] += red[threadIdx.x + s];
-			red[kBlock + threadIdx.x] += red[kBlock + threadIdx.x + s];
-			red[2 * kBlock + threadIdx.x] += red[2 * kBlock + threadIdx.x + s];
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
-		out->per_depth[depth] = red[0];
-		out->per_depth_shadow[depth] = red[kBlock];
-		out->per_depth_hits[depth] = red[2 * kBlock];
-		atomicAdd(&out->trace_rays, red[0]);
-		atomicAdd(&out->shadow_rays, red[kBlock]);
-		atomicAdd(&out->shaded_hits, red[2 * kBlock]);
-	}
-}
-
-// scene.root->intersect for arbitrary rays (parity tap + ptx_primary_hits)
-struct IntersectArgs {
-	DevScene S;
-	DevCamera cam;
-	const float* o;
-	const float* d;   // NULL => primary rays of sample `sample`
-	long long n;
-	unsigned sample;
-	int32_t* prim;
-	float* t;
-	float* pos;
-	float* nrm;
-	float* rdir;
-};
-__global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
-	__shared__ int lds_stack[kStack * kBlock];
-	int* stk = lds_stack + threadIdx.x;
-	for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < A.n; i += (long long) gridDim.x * kBlock) {
-		f3 o, d;
-		if (A.d) {
-			o = ld3(A.o + 3 * i);
-			d = ld3(A.d + 3 * i);
-		} else {
-			make_primary(A.cam, (unsigned) i, A.sample, o, d);
-		}
-		Hit h;
-		trace_closest(A.S, o, d, stk, h);
-		if (A.prim) A.prim[i] = h.id;
-		bool hit = h.id >= 0;
-		if (A.t) A.t[i] = hit ? h.t : 0.0f;
-		if (A.pos || A.nrm || A.rdir) {
-			Surface sf;
-			sf.pos = sf.n = sf.rdir = mk(0, 0, 0);
-			if (hit) sf = surface_of(A.S, o, d, h);
-			if (A.pos) { A.pos[3 * i] = sf.pos.x; A.pos[3 * i + 1] = sf.pos.y; A.pos[3 * i + 2] = sf.pos.z; }
-			if (A.nrm) { A.nrm[3 * i] = sf.n.x; A.nrm[3 * i + 1] = sf.n.y; A.nrm[3 * i + 2] = sf.n.z; }
-			if (A.rdir) { A.rdir[3 * i] = sf.rdir.x; A.rdir[3 * i + 1] = sf.rdir.y; A.rdir[3 * i + 2] = sf.rdir.z; }
-		}
-	}
-}
-
-// framework/renderer.cpp:86-89, :286-291 and ppmwriter.cpp:36-43
-__global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ accum, unsigned w, unsigned h, float inv_spp,
-                                                    float* __restrict__ color, uint8_t* __restrict__ rgb8) {
-	unsigned n = w * h;
-	for (unsigned p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
-		unsigned x = p % w, y = p / w;
-		float c[3];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			float v = accum[(size_t) p * 3 + k] * inv_spp;
-			v /= v + 1.0f;
-			c[k] = v;
-		}
-		if (color) {
-			color[(size_t) p * 3] = c[0];
-			color[(size_t) p * 3 + 1] = c[1];
-			color[(size_t) p * 3 + 2] = c[2];
-		}
-		if (rgb8) {
-			size_t q = 3 * ((size_t) w * (h - 1 - y) + x);
-#pragma unroll
-			for (int k = 0; k < 3; ++k) {
-				double v = 255.0 * (double) c[k];
-				v = (255.0 < v) ? 255.0 : v;  // std::min(255.0 * c, 255.0)
-				v = (0.0 < v) ? v : 0.0;      // std::max(0.0, .)
-				rgb8[q + k] = (uint8_t) (unsigned int) v;
-			}
-		}
-	}
-}
 
 // ---------------------------------------------------------------------------
 // host side
