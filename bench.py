@@ -85,12 +85,15 @@ def cpu_baseline(args, scene_path):
 
 
 def measured_traffic(args, kernel, launches):
-    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/r01_hbm_traffic.json,
-    written by scripts/pmc_summary.py --traffic), if they were taken on this workload: same scene,
-    size, spp and bounces, hence the same number of launches per step."""
-    path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed counter passes (the newest
+    profiles/*_hbm_traffic.json, written by scripts/pmc_summary.py --traffic), if they were taken
+    on this workload: same scene, size, spp, bounces and queue memory, hence the same launches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
     try:
-        with open(path) as f:
+        with open(files[-1]) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return None

@@ -36,7 +36,7 @@ extern "C" {
 typedef enum PtxStatus {
 	PTX_OK = 0,
 	PTX_ERR_INVALID = 1,     /* bad argument / malformed scene description            */
-	PTX_ERR_UNSUPPORTED = 2, /* scene shape this build does not flatten (see DESIGN)  */
+	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (nested transformed Composites, non-triangle leaves inside a mesh) */
 	PTX_ERR_DEVICE = 3,      /* HIP call failed, or no gfx950 device                  */
 	PTX_ERR_OVERFLOW = 4,    /* a ray queue filled up: result discarded, see message  */
 	PTX_ERR_NOMEM = 5
@@ -248,7 +248,7 @@ PtxStatus ptx_write_pfm(const char* path, const float* color, uint32_t width, ui
  */
 PtxStatus ptx_scene_set_profiling(PtxScene* scene, int enable);
 
-/* Introspection for tests and DESIGN numbers: BVH node / leaf-triangle counts, depth. */
+/* Introspection for tests and measurements: frames, prims, BVH nodes, BVH depth, device bytes. */
 PtxStatus ptx_scene_info(const PtxScene* scene, int32_t* n_frames, int32_t* n_prims, int32_t* n_bvh_nodes,
                          int32_t* max_bvh_depth, uint64_t* device_bytes);
 

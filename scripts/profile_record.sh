@@ -1,9 +1,9 @@
 #!/bin/bash
-# The round's measurement record (run on the GPU box from the repo root):
+# The measurement record kept under profiles/ (run on the GPU box from the repo root):
 #   1. bench.py with its default arguments            -> $OUT/bench.json
 #   2. rocprofv3 --kernel-trace --stats of the bench  -> $OUT/kernel_stats.csv (+ bench line)
 #   3. counter passes, one group per run              -> $OUT/pmc/, summary + HBM traffic per launch
-# usage: scripts/profile_round.sh gpurun_out/r1
+# usage: scripts/profile_record.sh gpurun_out/rec
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/$1
