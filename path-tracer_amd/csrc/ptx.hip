@@ -141,42 +141,45 @@ void camera_basis(const PtxCamera& c, const PtxRenderParams& rp, DevCamera& out)
 	out.pad = 0;
 }
 
-// Bounding sphere of a frame-0 leaf in frame-0 space for may_hit_sphere: (centre, R^2) with R
-// padded by 0.1 % + 0.001 so that the filter's own rounding can never reject a ray the exact
-// test accepts.  A transformed leaf's local sphere is carried through its matrix: centre
-// mapped, radius times the Frobenius norm of the linear part (an upper bound of its stretch).
-float4 bounding_sphere(const PtxPrim& P) {
-	double c[3], r;
-	if (P.kind == PTX_SPHERE) {
-		for (int k = 0; k < 3; ++k) c[k] = P.p[k];
-		r = std::fabs((double) P.p[3]);
-	} else if (P.kind == PTX_BOX) {
-		double h2 = 0;
-		for (int k = 0; k < 3; ++k) {
-			c[k] = 0.5 * ((double) P.p[k] + P.p[3 + k]);
-			double h = 0.5 * ((double) P.p[3 + k] - P.p[k]);
-			h2 += h * h;
-		}
-		r = std::sqrt(h2);
-	} else {
-		for (int k = 0; k < 3; ++k) c[k] = ((double) P.p[k] + P.p[3 + k] + P.p[6 + k]) / 3.0;
-		r = 0;
-		for (int v = 0; v < 3; ++v) {
-			double d2 = 0;
-			for (int k = 0; k < 3; ++k) d2 += (P.p[3 * v + k] - c[k]) * (P.p[3 * v + k] - c[k]);
-			r = std::max(r, std::sqrt(d2));
+// Bounding box of a frame-0 leaf in frame-0 space for may_hit_box: the leaf's local box (a
+// sphere's is centre +- radius) carried through its matrix corner by corner, then padded by
+// 0.01 % + 0.001 so that the filter's own rounding can never reject a ray the exact test
+// accepts.  Anything non-finite gives an infinite box (never rejects).
+void bounding_box(const PtxPrim& P, float4& lo, float4& hi) {
+	double l[3], h[3];
+	for (int k = 0; k < 3; ++k) {
+		if (P.kind == PTX_SPHERE) {
+			l[k] = (double) P.p[k] - std::fabs((double) P.p[3]);
+			h[k] = (double) P.p[k] + std::fabs((double) P.p[3]);
+		} else if (P.kind == PTX_BOX) {
+			l[k] = std::min<double>(P.p[k], P.p[3 + k]);
+			h[k] = std::max<double>(P.p[k], P.p[3 + k]);
+		} else {
+			l[k] = std::min<double>(P.p[k], std::min<double>(P.p[3 + k], P.p[6 + k]));
+			h[k] = std::max<double>(P.p[k], std::max<double>(P.p[3 + k], P.p[6 + k]));
 		}
 	}
 	const float* W = P.world;  // column-major
-	double cw[3], fro = 0;
-	for (int k = 0; k < 3; ++k) cw[k] = W[k] * c[0] + W[4 + k] * c[1] + W[8 + k] * c[2] + W[12 + k];
-	for (int col = 0; col < 3; ++col)
-		for (int k = 0; k < 3; ++k) fro += (double) W[4 * col + k] * W[4 * col + k];
-	double R = r * std::sqrt(fro) * 1.001 + 1e-3;
-	float R2 = (float) (R * R);
-	R2 = std::nextafter(R2, std::numeric_limits<float>::infinity());
-	if (!(R2 >= 0.0f)) R2 = std::numeric_limits<float>::infinity();  // NaN: never reject
-	return make_float4((float) cw[0], (float) cw[1], (float) cw[2], R2);
+	const double inf = std::numeric_limits<double>::infinity();
+	double wl[3] = {inf, inf, inf}, wh[3] = {-inf, -inf, -inf};
+	bool finite = true;
+	for (int c = 0; c < 8; ++c) {
+		const double x = c & 1 ? h[0] : l[0], y = c & 2 ? h[1] : l[1], z = c & 4 ? h[2] : l[2];
+		for (int k = 0; k < 3; ++k) {
+			const double v = W[k] * x + W[4 + k] * y + W[8 + k] * z + W[12 + k];
+			finite = finite && std::isfinite(v);
+			wl[k] = std::min(wl[k], v);
+			wh[k] = std::max(wh[k], v);
+		}
+	}
+	float fl[3], fh[3];
+	for (int k = 0; k < 3; ++k) {
+		const double pad = 1e-4 * std::max(std::fabs(wl[k]), std::fabs(wh[k])) + 1e-3;
+		fl[k] = finite ? std::nextafter((float) (wl[k] - pad), -std::numeric_limits<float>::infinity()) : -std::numeric_limits<float>::infinity();
+		fh[k] = finite ? std::nextafter((float) (wh[k] + pad), std::numeric_limits<float>::infinity()) : std::numeric_limits<float>::infinity();
+	}
+	lo = make_float4(fl[0], fl[1], fl[2], 0.f);
+	hi = make_float4(fh[0], fh[1], fh[2], 0.f);
 }
 
 PtxStatus check_params(const PtxRenderParams* p) {
@@ -333,7 +336,12 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			Q.material = P.material;
 			root_prims.push_back(R);
 			root_shade.push_back(Q);
-			root_bound.push_back(bounding_sphere(P));
+			{
+				float4 blo, bhi;
+				bounding_box(P, blo, bhi);
+				root_bound.push_back(blo);
+				root_bound.push_back(bhi);
+			}
 		} else {
 			if (P.kind != PTX_TRIANGLE) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": only triangles may live inside a mesh frame");
 			if (!is_identity(P.world)) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": a mesh triangle must not carry its own transform");

@@ -97,7 +97,7 @@ struct DevScene {
 	PTX_KPTR(DevFrame) frames_k;
 	PTX_KPTR(Mat16) frame_winv_k;
 	PTX_KPTR(float4) lights_k;
-	PTX_KPTR(float4) root_bound_k;  // per frame-0 leaf: bounding sphere in frame-0 space (centre, padded radius squared)
+	PTX_KPTR(float4) root_bound_k;  // per frame-0 leaf: padded bounding box in frame-0 space, 2 x float4 (lo, hi)
 	int32_t n_root_prims, n_frames, n_lights, n_prims;
 	int32_t has_plain_sphere;
 	float ambient[3];
@@ -272,15 +272,17 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 // formed once: a shape whose transform is a pure translation sees the ray's direction
 // unchanged, so its reciprocals, unit vector and length are these very numbers.
 struct RayPre {
-	f3 inv;   // 1.0f / d
-	f3 dn;    // normalize(d)      (only when the scene holds a translated-only sphere)
+	f3 inv;     // 1.0f / d
+	f3 dn;      // normalize(d)      (only when the scene holds a translated-only sphere)
 	float len;  // length(d)
-	float dd;   // |d|^2, for the bounding-sphere filter only
+	f3 finv;    // finite reciprocal of d and -o * finv: the conservative bounding-box filter only
+	f3 fnoi;
 };
-__device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 d) {
+__device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 o, f3 d) {
 	RayPre r;
-	r.dd = __builtin_fmaf(d.x, d.x, __builtin_fmaf(d.y, d.y, d.z * d.z));
 	r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	r.finv = mk(bvh_rcp(d.x), bvh_rcp(d.y), bvh_rcp(d.z));
+	r.fnoi = mk(-(o.x * r.finv.x), -(o.y * r.finv.y), -(o.z * r.finv.z));
 	r.dn = mk(0, 0, 0);
 	r.len = 0;
 	if (S.has_plain_sphere) {
@@ -290,20 +292,19 @@ __device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 d) {
 	return r;
 }
 
-// Conservative filter in front of a leaf's exact test: false only if the ray's line stays
-// outside the leaf's padded bounding sphere, or the ray starts outside it and points away.
-// Like the BVH node test it never produces a value; whatever passes gets the reference's
-// arithmetic.  About a dozen instructions against 45 to 100 for an exact test, and a wave
-// whose 64 rays all fail (the usual case for rays of one pixel) skips the leaf altogether.
-// NaN or infinite intermediate values compare false and so pass.
-__device__ __forceinline__ bool may_hit_sphere(float4 bs, f3 o, f3 d, float dd) {
-	f3 oc = mk(bs.x - o.x, bs.y - o.y, bs.z - o.z);
-	float b = __builtin_fmaf(oc.x, d.x, __builtin_fmaf(oc.y, d.y, oc.z * d.z));
-	float c2 = __builtin_fmaf(oc.x, oc.x, __builtin_fmaf(oc.y, oc.y, oc.z * oc.z));
-	float lhs = __builtin_fmaf(c2, dd, -(b * b));               // |oc x d|^2, up to rounding of about 1e-7 * c2 * dd
-	float rhs = __builtin_fmaf(c2, 2e-6f, bs.w) * dd;           // (R^2 + slack for that rounding) * |d|^2
-	const bool away = b < 0.0f && c2 > bs.w;
-	return !(lhs > rhs) && !away;
+// Conservative filter in front of a leaf's exact test: false only if the ray cannot reach the
+// leaf's padded bounding box (slab test with fused multiply-adds on a finite reciprocal, like
+// the BVH node test).  It never produces a value; whatever passes gets the reference's
+// arithmetic.  16 instructions against 45 to 100 for an exact test, and a wave whose 64 rays
+// all fail (the usual case for the rays of one pixel: of the six walls of a room they see
+// one) skips the leaf altogether.  NaN compares false and so passes.
+__device__ __forceinline__ bool may_hit_box(float4 lo, float4 hi, const RayPre& pre) {
+	float ax = __builtin_fmaf(lo.x, pre.finv.x, pre.fnoi.x), bx = __builtin_fmaf(hi.x, pre.finv.x, pre.fnoi.x);
+	float ay = __builtin_fmaf(lo.y, pre.finv.y, pre.fnoi.y), by = __builtin_fmaf(hi.y, pre.finv.y, pre.fnoi.y);
+	float az = __builtin_fmaf(lo.z, pre.finv.z, pre.fnoi.z), bz = __builtin_fmaf(hi.z, pre.finv.z, pre.fnoi.z);
+	float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+	float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	return !(tn > tf);
 }
 
 // one leaf of frame 0 against a frame-0-space ray: the reference's per-shape intersect up
@@ -350,7 +351,7 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	float unused;
 	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return false;
 	for (int i = 0; i < S.n_root_prims; ++i) {
-		if (!__ballot(may_hit_sphere(kload(S.root_bound_k + i), o, d, pre.dd))) continue;
+		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
 		float t;
 		const bool hit = root_prim_t(S, P, o, d, pre, t);
@@ -387,7 +388,7 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 	}
 }
 __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
-	const RayPre pre = ray_pre(S, d);
+	const RayPre pre = ray_pre(S, o, d);
 	if (!closest_root(S, o, d, pre, best)) return;
 	closest_frames<false>(S, o, d, pre, 0u, stk, best);
 }
@@ -396,10 +397,10 @@ __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int
 // lies within `range`  <=>  some leaf is hit at distance <= range.
 __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
 	float t;
-	RayPre pre = ray_pre(S, d);
+	RayPre pre = ray_pre(S, o, d);
 	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, t)) return false;
 	for (int i = 0; i < S.n_root_prims; ++i) {
-		if (!__ballot(may_hit_sphere(kload(S.root_bound_k + i), o, d, pre.dd))) continue;
+		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
 		if (root_prim_t(S, P, o, d, pre, t) && t <= range) return true;
 	}
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			f3 o, d, w;
 			unsigned pix;
 			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
-			const RayPre pre = ray_pre(A.S, d);
+			const RayPre pre = ray_pre(A.S, o, d);
 			closest_frames<false>(A.S, o, d, pre, 0u, stk, h);
 		}
 		parked -= count;
@@ -982,10 +983,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		h.t = kInf;
 		f3 o = {0, 0, 0}, d = {0, 0, 1}, w;
 		unsigned pix, frames = 0;
-		RayPre pre = ray_pre(A.S, d);
+		RayPre pre = ray_pre(A.S, o, d);
 		if (i < n) {
 			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
-			pre = ray_pre(A.S, d);
+			pre = ray_pre(A.S, o, d);
 			if (closest_root(A.S, o, d, pre, h)) frames = frame_mask(A.S, o, d, pre);
 			++cnt_trace;
 		}
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 
 // find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
 // unblocked ray adds its contribution to its pixel
-__global__ __launch_bounds__(kBlock) void k_shadow(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ unsigned pfx[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
