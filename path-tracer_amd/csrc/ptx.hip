@@ -8,7 +8,7 @@
 //   wave are 64 samples of ONE pixel), for every depth d of the ray tree:
 //     k_trace    closest hit of every ray of depth d (d = 0: rays generated in registers, no
 //                primary-ray queue; d > 0: read from queue[d-1]): frame-0 leaves in lock step
-//                (wave-uniform scalar loads, a bounding-sphere filter in front of each exact
+//                (wave-uniform scalar loads, a bounding-box filter in front of each exact
 //                test) + one BVH2 walk per mesh frame with a per-lane stack in LDS; the hits
 //                are compacted into a list of 16-byte records
 //     k_shade    one lane per hit: surface point, Phong terms, <= 2 weighted child rays
