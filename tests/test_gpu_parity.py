@@ -389,3 +389,27 @@ def test_deepest_ray_trees(pt, port, tmp_path):
         assert r["stats"]["trace_rays"] <= int(ref["counters"][0])
     with pytest.raises(pt.PtxError):
         small.render_image(w, h, aa, 64)
+
+
+def test_scene_lifecycle(pt, scenes):
+    """Scenes are independent objects: creating, using and destroying many of them, and using two
+    alternately, gives the same images every time and leaves no device memory behind."""
+    import torch
+    hs_a, hs_b = scenes.host_scene("cornell"), scenes.host_scene("example_fixed")
+    ref_a = scenes.device_scene("cornell").render_image(64, 40, 2, 3)
+    ref_b = scenes.device_scene("example_fixed").render_image(64, 40, 2, 3)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(12):
+        a = pt.DeviceScene(hs_a, 0, 1 << 27)
+        b = pt.DeviceScene(hs_b, 0, 1 << 27)
+        ra = a.render_image(64, 40, 2, 3, pipeline=PIPELINES[k % 2])
+        rb = b.render_image(64, 40, 2, 3, pipeline=PIPELINES[(k + 1) % 2])
+        ra2 = a.render_image(64, 40, 2, 3)
+        assert_image_close(ra["color"], ref_a["color"], ra["rgb"], ref_a["rgb"])
+        assert_image_close(rb["color"], ref_b["color"], rb["rgb"], ref_b["rgb"])
+        assert_image_close(ra2["color"], ref_a["color"], ra2["rgb"], ref_a["rgb"])
+        a.close()
+        b.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
