@@ -413,3 +413,24 @@ def test_scene_lifecycle(pt, scenes):
         b.close()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_example_program(pt, tmp_path):
+    """The reference's demo main rebuilt against this library (csrc/host/example.cpp): a C++
+    program with no Python in it loads cornell.sdf, renders, writes the reference's PPM."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pt.__file__), "pt_example")
+    assert os.path.exists(exe), "build it with make -C path-tracer_amd/csrc"
+    g = load_golden("cornell")
+    w, h, aa, nb = (int(v) for v in g["params"])
+    out = tmp_path / "img.ppm"
+    r = subprocess.run([exe, pt.SDF_DIR + "/cornell.sdf", str(out), str(w), str(h), str(aa), str(nb)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "shapes" in r.stdout and "s rendering" in r.stdout
+    text = out.read_bytes()
+    vals = np.array(text.split()[4:], dtype=np.int32).astype(np.uint8).reshape(h, w, 3)
+    bd = np.abs(vals.astype(int) - g["rgb"].astype(int))
+    assert (bd > 0).mean() <= 1e-3 and bd.max() <= 1
+    r = subprocess.run([exe, str(tmp_path / "missing.sdf"), str(out)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Exception" in r.stdout
