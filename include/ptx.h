@@ -158,7 +158,7 @@ typedef struct PtxStats {
 	uint64_t trace_rays;   /* closest-hit queries (primary + reflection + refraction) */
 	uint64_t shadow_rays;  /* any-hit queries                                        */
 	uint64_t shaded_hits;  /* hits that were shaded                                  */
-	uint64_t launches;     /* bounce-kernel launches                                 */
+	uint64_t launches;     /* kernel launches                                        */
 	uint64_t per_depth_rays[16];    /* closest-hit queries per ray-tree depth          */
 	uint64_t per_depth_shadow[16];  /* any-hit queries issued at that depth            */
 	uint64_t per_depth_hits[16];    /* shaded hits at that depth                       */
@@ -188,8 +188,11 @@ void ptx_scene_destroy(PtxScene* scene);
 /*
  * Adds, for every pixel, the sum over the selected samples of trace(primary ray)
  * (framework/renderer.cpp:74-85) to d_accum (w*h*3 floats, row-major, y up, NOT cleared
- * here).  Asynchronous on `stream` except for one final readback of the overflow flag
- * and statistics when `stats` is non-NULL or check_overflow is non-zero.
+ * here).  All device work goes to `stream`.  The call waits on that stream once per chunk of
+ * primary samples when the scene spawns secondary rays (it reads the queue counters; a chunk
+ * is as many samples as the queue memory is certain to hold the ray tree of), and once at the
+ * end for the overflow flag and the statistics when `stats` is non-NULL or check_overflow is
+ * non-zero.  Rays are never dropped silently: PTX_ERR_OVERFLOW if a queue ever filled up.
  */
 PtxStatus ptx_render_accumulate(PtxScene* scene, const PtxRenderParams* params, float* d_accum, void* stream,
                                 int check_overflow, PtxStats* stats);

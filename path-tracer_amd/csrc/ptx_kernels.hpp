@@ -60,7 +60,7 @@ struct DevXform {  // full matrices of a leaf whose transform rotates or scales
 struct DevRootShade {  // what shading needs of a frame-0 leaf, per root slot
 	float tw[3];  // translation column of world_transform_ (kept for inspection; shading uses the full matrices)
 	int32_t material;
-	float n[3];   // triangle: n_
+	float n[3];   // triangle: the normal a hit reports, finished at upload
 	int32_t levels_in;
 };
 struct DevFrame {  // a mesh Composite with its own transform and bounds: 64-B head + matrices
@@ -87,7 +87,7 @@ struct DevScene {
 	const Mat16* frame_w;
 	const float4* nodes;      // 4 float4 per node
 	const float4* tris;       // 3 float4 per triangle: (v0, e1.x) (e1.yz, e2.xy) (e2.z, id, -, -)
-	const float4* prim_info;  // per prim id: (n.x, n.y, n.z, bits(material | levels_in << 16))
+	const float4* prim_info;  // per prim id: the normal a hit on a triangle reports, finished at upload (w: bits(material | levels_in << 16))
 	const float4* materials;  // 4 float4 per PRIM id (its material, so that a hit needs no second, dependent fetch):
 	                          // (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
 	const float4* lights;     // 2 float4 per light: (pos, -) (intensity, -)
