@@ -85,9 +85,9 @@ struct PtxScene {
 	DevScene dev{};
 	PtxCamera camera{};
 	std::vector<void*> allocs;
-	float4* qmem = nullptr;  // one block of ray records (48 B each), cut into queues per render
-	uint64_t qrays = 0;      // ray slots in qmem
-	unsigned* d_counts = nullptr;  // queue counters, one per depth, each on its own 256-B line
+	float4* qmem = nullptr;  // one block of work memory, cut per render into ray queues, a shadow queue and a hit list
+	uint64_t qrays = 0;      // its size in 48-byte slots
+	unsigned* d_counts = nullptr;  // tail counters: per depth 64 sub-queue tails, 128 B apart, for rays, shadow rays and hits
 	Counters* d_counters = nullptr;
 	unsigned long long* d_stat = nullptr;
 	bool branching = false;  // some material spawns two children per hit
