@@ -91,6 +91,27 @@ def test_ppm_text_is_byte_identical(pt, port, tmp_path):
         assert text.startswith(b"P3 %d %d 255 \n" % (g["rgb"].shape[1], g["rgb"].shape[0]))
 
 
+@pytest.mark.parametrize("text,outcome", [
+    ("define material m 1 1 1 1 1 1 1 1 1 10\ndefine shape sphere s 0 0 -5 1 m\ntransform nosuch translate 1 2 3\n", "no child named"),
+    ("define shape sphere s 0 0 -5 1 nosuchmat\n", "unknown material"),
+    ("define shape obj nosuchobj\n", "cannot open"),
+    ("hello world\ndefine\ndefine shape\ndefine shape blob x\ntransform\n", "no child named"),
+    ("define material m 1 1 1 1 1 1 1 1 1 10\ndefine shape sphere s 0 0\n", "unknown material"),
+    ("define material m 1 1 1 1 1 1 1 1 1 10\ndefine shape sphere a 0 0 -5 1 m\ndefine shape sphere a 1 0 -5 1 m\n", 1),
+    ("", 0),
+])
+def test_malformed_scenes_fail_cleanly(pt, tmp_path, text, outcome):
+    """Where the reference dereferences a null child or reads uninitialised operands
+    (scene.cpp:128-400), the loader here reports an error or loads what is well defined."""
+    f = tmp_path / "bad.sdf"
+    f.write_text(text)
+    if isinstance(outcome, str):
+        with pytest.raises(RuntimeError, match=outcome):
+            pt.HostScene(str(f))
+    else:
+        assert pt.HostScene(str(f)).desc.contents.n_prims == outcome
+
+
 def test_binary_writers(pt, tmp_path):
     """P6 and PFM carry the same rows / the same floats as the buffers handed in."""
     import numpy as np
