@@ -179,8 +179,11 @@ int ptx_device_count(void);
 
 /*
  * Validates and uploads a scene to `device`, builds the per-frame BVHs and allocates the
- * ray queues.  queue_bytes = HBM budget for the ray queues (0 = default 4 GiB).
+ * ray queues.  queue_bytes = HBM budget for the ray queues (0 = default 4 GiB; at least
+ * 96 MiB is taken; more memory means fewer, larger kernel launches, never different results).
  * Replaces the per-thread Scene copies of framework/renderer.cpp:48.
+ * A PtxScene owns its queues and counters: use it from one thread (one render) at a time;
+ * different scenes are independent.  ptx_last_error() is per thread.
  */
 PtxStatus ptx_scene_create(const PtxSceneDesc* desc, int device, uint64_t queue_bytes, PtxScene** out);
 void ptx_scene_destroy(PtxScene* scene);
