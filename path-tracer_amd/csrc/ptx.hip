@@ -182,6 +182,8 @@ void bounding_box(const PtxPrim& P, float4& lo, float4& hi) {
 	hi = make_float4(fh[0], fh[1], fh[2], 0.f);
 }
 
+constexpr int kRootBvhMin = 16;  // leaves of frame 0 from which they get a BVH of their own
+
 PtxStatus check_params(const PtxRenderParams* p) {
 	if (!p) return fail(PTX_ERR_INVALID, "params is NULL");
 	if (p->width == 0 || p->height == 0 || p->aa_steps == 0) return fail(PTX_ERR_INVALID, "width, height and aa_steps must be positive");
@@ -396,6 +398,46 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			tris.push_back(make_float4(e2[2], idf, 0, 0));
 		}
 	}
+	// ---- many leaves in frame 0: a BVH of their own over the padded bounding boxes (the filter
+	// boxes), the four per-leaf tables put into its leaf order.  Up to kRootBvhMin leaves the
+	// wave-uniform list with its scalar loads is the faster way.
+	int root_bvh_min = kRootBvhMin;
+	if (const char* e = std::getenv("PTX_ROOT_BVH_MIN")) root_bvh_min = std::max(0, std::atoi(e));
+	if ((int) root_prims.size() > root_bvh_min) {
+		std::vector<ptx::Aabb> boxes(root_prims.size());
+		bool finite = true;
+		for (size_t k = 0; k < boxes.size(); ++k) {
+			const float4 lo = root_bound[2 * k], hi = root_bound[2 * k + 1];
+			boxes[k] = {{lo.x, lo.y, lo.z}, {hi.x, hi.y, hi.z}};
+			finite = finite && std::isfinite(lo.x) && std::isfinite(lo.y) && std::isfinite(lo.z) && std::isfinite(hi.x) && std::isfinite(hi.y) && std::isfinite(hi.z);
+		}
+		if (finite) {
+			ptx::Bvh bvh = ptx::build_bvh(boxes);
+			if (bvh.max_depth > kStack) return fail(PTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+			sc->max_depth = std::max(sc->max_depth, bvh.max_depth);
+			std::vector<DevRootPrim> rp(root_prims.size());
+			std::vector<DevRootShade> rs(root_prims.size());
+			std::vector<DevXform> rx(root_prims.size());
+			std::vector<float4> rb(root_bound.size());
+			for (size_t k = 0; k < bvh.order.size(); ++k) {
+				const int32_t from = bvh.order[k];
+				rp[k] = root_prims[from];
+				rp[k].xform = (int32_t) k;
+				rs[k] = root_shade[from];
+				rx[k] = xforms[from];
+				rb[2 * k] = root_bound[2 * from];
+				rb[2 * k + 1] = root_bound[2 * from + 1];
+			}
+			root_prims.swap(rp);
+			root_shade.swap(rs);
+			xforms.swap(rx);
+			root_bound.swap(rb);
+			sc->dev.root_bvh = 1;
+			sc->dev.root_bvh_root = bvh.root_ref;
+			sc->dev.root_node_base = (int32_t) nodes.size() * 4;
+			nodes.insert(nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+		}
+	}
 	sc->n_nodes = (int) nodes.size();
 
 	PtxStatus st;
@@ -558,6 +600,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	auto hit_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kCountsPerDepth; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
+	const bool rb = sc->dev.root_bvh != 0;  // (the fused kernel has no such variant: it takes the leaves one by one)
 	// persistent grids: as many blocks as the kernel can keep resident on the device, times
 	// kGridRounds so that blocks which finish early are replaced; never more than `useful`
 	auto grid_of = [&](auto kern, uint64_t useful) -> unsigned {
@@ -583,8 +626,10 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		A.shadow_count = shadow_count_of(d);
 		A.hit_count = hit_count_of(d);
 		HIP_TRY(tick(0, d, true));
-		if (d == 0) hipLaunchKernelGGL(k_trace<true>, dim3(grid_of(k_trace<true>, useful)), dim3(kBlock), 0, stream, A);
-		else hipLaunchKernelGGL(k_trace<false>, dim3(grid_of(k_trace<false>, useful)), dim3(kBlock), 0, stream, A);
+		{
+			auto kern = d == 0 ? (rb ? k_trace<true, true> : k_trace<true, false>) : (rb ? k_trace<false, true> : k_trace<false, false>);
+			hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
+		}
 		HIP_TRY(tick(0, d, false));
 		HIP_TRY(tick(1, d, true));
 		auto kern = d == 0 ? (ip ? k_shade<true, true> : k_shade<true, false>) : (ip ? k_shade<false, true> : k_shade<false, false>);
@@ -592,7 +637,8 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
-			hipLaunchKernelGGL(k_shadow, dim3(grid_of(k_shadow, useful)), dim3(kBlock), 0, stream, A);
+			auto kern = rb ? k_shadow<true> : k_shadow<false>;
+			hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(2, d, false));
 			launches += 1;
 		}
@@ -850,7 +896,7 @@ static PtxStatus run_intersect(PtxScene* sc, IntersectArgs& A, int64_t n, int32_
 	A.rdir = static_cast<float*>(d_rd);
 	unsigned grid = (unsigned) std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t) sc->grid);
 	if (grid == 0) grid = 1;
-	hipLaunchKernelGGL(k_intersect, dim3(grid), dim3(kBlock), 0, nullptr, A);
+	hipLaunchKernelGGL(sc->dev.root_bvh ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kBlock), 0, nullptr, A);
 	TRY_C(hipGetLastError());
 	TRY_C(hipDeviceSynchronize());
 	if (prim) TRY_C(hipMemcpy(prim, d_prim, (size_t) n * 4, hipMemcpyDeviceToHost));

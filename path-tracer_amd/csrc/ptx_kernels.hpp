@@ -100,6 +100,9 @@ struct DevScene {
 	PTX_KPTR(float4) root_bound_k;  // per frame-0 leaf: padded bounding box in frame-0 space, 2 x float4 (lo, hi)
 	int32_t n_root_prims, n_frames, n_lights, n_prims;
 	int32_t has_plain_sphere;
+	int32_t root_bvh;        // != 0: the leaves of frame 0 are many and sit under a BVH of their own (root_walk)
+	int32_t root_bvh_root;   // its root reference
+	int32_t root_node_base;  // first float4 of its nodes in `nodes`
 	float ambient[3];
 	float root_min[3], root_max[3];
 };
@@ -336,6 +339,95 @@ __device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, 
 	}
 }
 
+// The same test with the leaf chosen per lane (ordinary loads instead of scalar ones): the
+// leaves of a large frame 0 are reached through a BVH, and lanes arrive at different ones.
+__device__ __forceinline__ bool root_prim_t_lane(const DevScene& S, int slot, f3 o, f3 d, const RayPre& pre, float& t, int& id) {
+	const DevRootPrim& P = S.root_prims[slot];
+	const int kf = P.kind_flags, kind = kf & 0xff;
+	id = P.id;
+	if (kf & kPlain) {
+		f3 lo = o + ld3(P.tinv);
+		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
+		if (kind == PTX_BOX) return box_slab_inv(ld3(P.p), ld3(P.p + 3), lo, d, pre.inv, t);
+		return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, d, t);
+	}
+	const float* Wi = S.xforms[slot].winv;
+	f3 lo = xform_point(Wi, o), ld = xform_dir(Wi, d);
+	if (kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
+	if (kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
+	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
+}
+
+// bvh_walk over the leaves of frame 0 (built over their padded bounding boxes when there are
+// more than a handful; the reference walks its root's children one by one,
+// composite.cpp:75-103).  Same conservative node test, same two nested loops; a leaf holds up
+// to four shapes of any kind, each tested with the reference's arithmetic.
+template <bool ANY>
+__device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const RayPre& pre, int* __restrict__ stk, Hit& best, float range) {
+	const float4* __restrict__ nodes = S.nodes + S.root_node_base;
+	const f3 inv = pre.finv, noi = pre.fnoi;
+	constexpr int kDone = (int) 0x80000000;
+	int sp = 0;
+	int cur = S.root_bvh_root;
+	float limit = ANY ? cull_limit(range) : cull_limit(best.t);
+	while (cur != kDone) {
+		while (cur >= 0) {
+			const float4* nd = nodes + (size_t) cur * 4;
+			float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+			float tn0, tn1;
+			bool h0, h1;
+			bvh_slab2(q0, q1, q2, inv, noi, limit, tn0, h0, tn1, h1);
+			int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+			if (h0 && h1) {
+				if (tn1 < tn0) {
+					int tmp = c0;
+					c0 = c1;
+					c1 = tmp;
+				}
+				stk[sp * kBlock] = c1;
+				++sp;
+				cur = c0;
+			} else if (h0) {
+				cur = c0;
+			} else if (h1) {
+				cur = c1;
+			} else if (sp > 0) {
+				--sp;
+				cur = stk[sp * kBlock];
+			} else {
+				cur = kDone;
+			}
+		}
+		if (cur == kDone) break;
+		{
+			int v = ~cur;
+			int first = v >> 3, cnt = (v & 7) + 1;
+			for (int k = 0; k < cnt; ++k) {
+				float t;
+				int id;
+				if (root_prim_t_lane(S, first + k, o, d, pre, t, id)) {
+					if (ANY) {
+						if (t <= range) return true;
+					} else if (t < best.t || (t == best.t && id < best.id)) {
+						best.t = t;
+						best.id = id;
+						best.frame = 0;
+						best.slot = first + k;
+						limit = cull_limit(t);
+					}
+				}
+			}
+		}
+		if (sp > 0) {
+			--sp;
+			cur = stk[sp * kBlock];
+		} else {
+			cur = kDone;
+		}
+	}
+	return false;
+}
+
 // scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103.
 // In parts, so that the closest-hit kernel can run the mesh walks of several steps together
 // (see k_trace):
@@ -343,13 +435,20 @@ __device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, 
 //   frame_mask      bit f set: the ray enters the bounds of mesh frame f (frames 1..31; bit 0
 //                   set: there are frames beyond 31, which closest_frames tests itself)
 //   closest_frames  the mesh frames; with `known` a frame below 32 is walked iff its bit is set
-__device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, const RayPre& pre, Hit& best) {
+// (RB: the kernel variant for scenes whose frame-0 leaves sit under a BVH; the variant without
+// it still gives the same answers on such a scene, leaf by leaf)
+template <bool RB>
+__device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, const RayPre& pre, int* __restrict__ stk, Hit& best) {
 	best.t = kInf;
 	best.id = -1;
 	best.frame = 0;
 	best.slot = 0;
 	float unused;
 	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return false;
+	if (RB && S.root_bvh) {
+		root_walk<false>(S, o, d, pre, stk, best, 0.0f);
+		return true;
+	}
 	for (int i = 0; i < S.n_root_prims; ++i) {
 		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
@@ -387,24 +486,30 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f);
 	}
 }
+template <bool RB = false>
 __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
 	const RayPre pre = ray_pre(S, o, d);
-	if (!closest_root(S, o, d, pre, best)) return;
+	if (!closest_root<RB>(S, o, d, pre, stk, best)) return;
 	closest_frames<false>(S, o, d, pre, 0u, stk, best);
 }
 
 // find_light_block(...).does_intersect, framework/renderer.cpp:168-175: the closest hit
 // lies within `range`  <=>  some leaf is hit at distance <= range.
+template <bool RB = false>
 __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
 	float t;
 	RayPre pre = ray_pre(S, o, d);
 	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, t)) return false;
-	for (int i = 0; i < S.n_root_prims; ++i) {
-		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
-		const DevRootPrim P = kload(S.root_prims_k + i);
-		if (root_prim_t(S, P, o, d, pre, t) && t <= range) return true;
-	}
 	Hit dummy;
+	if (RB && S.root_bvh) {
+		if (root_walk<true>(S, o, d, pre, stk, dummy, range)) return true;
+	} else {
+		for (int i = 0; i < S.n_root_prims; ++i) {
+			if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
+			const DevRootPrim P = kload(S.root_prims_k + i);
+			if (root_prim_t(S, P, o, d, pre, t) && t <= range) return true;
+		}
+	}
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
@@ -921,7 +1026,7 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 // small ring in LDS and walks once 64 of them have gathered, with every lane busy at the start.
 constexpr unsigned kRing = 128;    // parked rays per wave
 constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
-template <bool PRIMARY>
+template <bool PRIMARY, bool RB>
 __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ unsigned pfx[kNQ + 1];
@@ -987,7 +1092,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		if (i < n) {
 			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
 			pre = ray_pre(A.S, o, d);
-			if (closest_root(A.S, o, d, pre, h)) frames = frame_mask(A.S, o, d, pre);
+			if (closest_root<RB>(A.S, o, d, pre, stk, h)) frames = frame_mask(A.S, o, d, pre);
 			++cnt_trace;
 		}
 		bool park = frames != 0;
@@ -1108,6 +1213,7 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 
 // find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
 // unblocked ray adds its contribution to its pixel
+template <bool RB>
 __global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ unsigned pfx[kNQ + 1];
@@ -1133,7 +1239,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 			f3 ldir = mk(lp.x, lp.y, lp.z) - pos;
 			const float dist = length(ldir);
 			ldir = normalize(ldir);
-			lit = !trace_any(A.S, pos, ldir, dist, stk);
+			lit = !trace_any<RB>(A.S, pos, ldir, dist, stk);
 		}
 		accumulate(A.accum, pix, c, lit);
 	}
@@ -1186,6 +1292,7 @@ struct IntersectArgs {
 	float* nrm;
 	float* rdir;
 };
+template <bool RB>
 __global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	int* stk = lds_stack + threadIdx.x;
@@ -1198,7 +1305,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
 			make_primary(A.cam, (unsigned) i, A.sample, o, d);
 		}
 		Hit h;
-		trace_closest(A.S, o, d, stk, h);
+		trace_closest<RB>(A.S, o, d, stk, h);
 		if (A.prim) A.prim[i] = h.id;
 		bool hit = h.id >= 0;
 		if (A.t) A.t[i] = hit ? h.t : 0.0f;
