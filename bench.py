@@ -213,14 +213,14 @@ def main():
             staged = kln[1][0] > 0
             rays0, shadow0, hits0 = stats["per_depth_rays"][0], stats["per_depth_shadow"][0], stats["per_depth_hits"][0]
             if staged:
-                name = "k_trace<true> (depth 0: ray generation + closest hit -> hit records)"
+                name = "k_trace<true, false> (depth 0: ray generation + closest hit -> hit records)"
                 bytes0 = (48 + 16) * rays0
             else:
                 name = "k_bounce<true> (depth 0: ray generation + closest hit + shading + shadow + emit + accumulate)"
                 bytes0 = BYTES_PER_RAY * (rays0 + shadow0) + BYTES_PER_HIT * hits0
             achieved = bytes0 / (ms0 * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, "k_trace<true>" if staged else "k_bounce<true, true>", n0),
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, "k_trace<true, false>" if staged else "k_bounce<true, true>", n0),
                                "launches": n0, "avg_launch_ms": ms0 / n0, "algorithmic_bytes_per_launch": bytes0 / n0}
             tot_ms = sum(sum(r) for r in kms)
             tot_bytes = BYTES_PER_RAY * R + BYTES_PER_HIT * H

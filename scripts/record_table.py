@@ -31,7 +31,7 @@ traffic = json.load(open(d + '/hbm_traffic.json'))
 print('value %.0f Msamples/s, %.1f ms per image, roofline %s' % (bench['value'], bench['ms_per_step'], json.dumps(bench['roofline'])))
 print('| kernel | ms | HBM traffic | vector ALU busy | lanes active in VALU instr. | waves parked (SQ_WAIT_ANY) | L1 hit | fp32 FMA+MUL |')
 tot_t = tot_b = 0
-for k in ('k_trace<true>', 'k_trace<false>', 'k_shade<true, true>', 'k_shade<false, true>', 'k_shadow'):
+for k in ('k_trace<true, false>', 'k_trace<false, false>', 'k_shade<true, true>', 'k_shade<false, true>', 'k_shadow<false>'):
     c = data[k]
     t = ns[k] * 1e-9
     simd_cycles = t * 2.4e9 * 1024
