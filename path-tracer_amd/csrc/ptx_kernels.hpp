@@ -739,31 +739,34 @@ __device__ __forceinline__ unsigned long long lanes_below(unsigned lane) { retur
 // consecutive lanes with equal pixel (rays stay in pixel order through compaction), each
 // run is summed with shuffles and its first lane issues the three atomics.
 __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned pix, f3 v, bool has) {
-	if (__ballot(has) == 0) return;
-	unsigned lane = lane_id();
+	const unsigned long long has_mask = __ballot(has);
+	if (has_mask == 0) return;
+	const unsigned lane = lane_id();
 	if (!has) v = mk(0, 0, 0);
-	unsigned up = __shfl_up(pix, 1);
-	bool head = lane == 0 || up != pix;
-	unsigned long long heads = __ballot(head);
-	unsigned seg = __builtin_popcountll(heads & (lanes_below(lane) | (1ull << lane)));  // run number, non-decreasing
-	int any = has ? 1 : 0;
+	const unsigned up = __shfl_up(pix, 1);
+	const bool head = lane == 0 || up != pix;
+	const unsigned long long heads = __ballot(head);
+	// run heads above this lane (bit 0 = lane + 1): lane + off belongs to my run iff none of the
+	// low `off` bits is set - the run bookkeeping needs no shuffles of its own
+	const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
 #pragma unroll
 	for (int off = 1; off < 64; off <<= 1) {
 		float ox = __shfl_down(v.x, off), oy = __shfl_down(v.y, off), oz = __shfl_down(v.z, off);
-		unsigned os = __shfl_down(seg, off);
-		int oa = __shfl_down(any, off);
-		if (lane + off < 64 && os == seg) {
+		if (lane + off < 64 && (above & ((1ull << off) - 1)) == 0) {
 			v.x += ox;
 			v.y += oy;
 			v.z += oz;
-			any |= oa;
 		}
 	}
-	if (head && any) {
-		float* p = accum + (size_t) pix * 3;
-		atomicAdd(p, v.x);
-		atomicAdd(p + 1, v.y);
-		atomicAdd(p + 2, v.z);
+	if (head) {
+		const unsigned run = above ? (unsigned) __builtin_ctzll(above) + 1 : 64 - lane;  // lanes in my run
+		const unsigned long long mine = has_mask >> lane;
+		if (run >= 64 ? mine != 0 : (mine & ((1ull << run) - 1)) != 0) {
+			float* p = accum + (size_t) pix * 3;
+			atomicAdd(p, v.x);
+			atomicAdd(p + 1, v.y);
+			atomicAdd(p + 2, v.z);
+		}
 	}
 }
 
