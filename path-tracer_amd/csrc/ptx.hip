@@ -93,7 +93,7 @@ struct PtxScene {
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
 	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
-	unsigned n_cus = 0, grid_rounds = 3;
+	unsigned n_cus = 0, grid_rounds = 4;
 	std::map<const void*, unsigned> resident_blocks;  // per kernel: blocks the device keeps resident at once
 	bool profiling = false;
 	std::vector<hipEvent_t> events;      // pairs, reused from call to call
