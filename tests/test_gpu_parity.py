@@ -495,3 +495,51 @@ def test_many_root_shapes(pt, port, tmp_path):
     for pipeline in PIPELINES:
         r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
         assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+
+
+def test_reference_unit_test_cases_on_device(pt, port, tmp_path):
+    """The cases of the reference's own source/tests.cpp as one-shape scenes on the device (the
+    shape sits under the root Composite, which only re-normalises the normal), with the values
+    the code gives today: every intersector subtracts EPSILON = 0.001 from t."""
+    eps = np.float32(0.001)
+    mat = "define material m 1 1 1 1 1 1 0 0 0 0 0 1 1\n"
+
+    def scene(text):
+        f = tmp_path / ("s%d.sdf" % abs(hash(text)))
+        f.write_text(mat + text)
+        return pt.DeviceScene(pt.HostScene(str(f)), 0, 1 << 27), port.load(str(f))
+
+    def both(ds_s, o, d):
+        ds, s = ds_s
+        a, b = ds.intersect(o, d), port.intersect(s, o, d)
+        assert np.array_equal(a["prim"], b["rank"])
+        m = b["hit"]
+        for k in ("t", "pos", "normal", "raydir"):
+            assert beq(a[k][m], b[k][m]), k
+        return a
+
+    # tests.cpp:76-96 intersect_ray_sphere2: hit at 8 - eps, miss, tangent
+    for cx, expect in ((0, 7.999), (4, None), (2, 9.999)):
+        a = both(scene(f"define shape sphere s {cx} 0 10 2 m\n"), [[0, 0, 0]], [[0, 0, 1]])
+        if expect is None:
+            assert a["prim"][0] == -1
+        else:
+            assert a["prim"][0] == 0 and abs(float(a["t"][0]) - expect) < 1e-3
+    a = both(scene("define shape sphere s 0 0 10 2 m\n"), [[0, 0, 0]], [[0, 0, 1]])
+    assert a["t"][0] == np.float32(8.0) - eps and np.allclose(a["pos"][0], [0, 0, 7.999], atol=1e-6)
+    # tests.cpp:112-142 box_ray_intersection
+    a = both(scene("define shape box b -10 -10 -10 10 10 10 m\n"),
+             [[5, 5, -20], [20, 20, 0], [-20, -20, -20], [10, 30, 10], [0, 0, 20]], [[0, 0, 1], [0, 0, 1], [1, 20, 1], [-1, -1, -1], [0, 0, 1]])
+    assert list(a["prim"] >= 0) == [True, False, False, True, False]
+    assert a["t"][0] == np.float32(10.0) - eps and a["t"][3] == np.float32(20.0) - eps
+    assert np.allclose(a["pos"][0], [5, 5, -10], atol=1.1e-3) and np.allclose(a["pos"][3], [-10, 10, -10], atol=1.1e-3)
+    # tests.cpp:144-158 triangle_ray_intersection
+    a = both(scene("define shape triangle t -1 0 -1 0 0 1 1 0 -1 m\n"), [[0, 10, 0], [1, 10, 1], [10, 0, 0]], [[0, -1, 0], [0, -1, 0], [-1, 0, 0]])
+    assert list(a["prim"] >= 0) == [True, False, False]
+    # tests.cpp:160-176 composite_ray_intersection: the nearer child wins
+    ds_s = scene("define shape sphere back 0 0 -1 1 m\ndefine shape box front -1 -1 0 1 1 2 m\n")
+    a = both(ds_s, [[0, 10, 1], [0, 10, -1]], [[0, -1, 0], [0, -1, 0]])
+    assert a["prim"][0] != a["prim"][1] and (a["prim"] >= 0).all()
+    # tests.cpp:252-259 scale sphere: position (0,0,2.001), normal (0,0,1)
+    a = both(scene("define shape sphere s 0 0 0 1 m\ntransform s scale 2 2 2\n"), [[0, 0, 10]], [[0, 0, -1]])
+    assert a["prim"][0] == 0 and np.allclose(a["pos"][0], [0, 0, 2.001], atol=1e-5) and np.allclose(a["normal"][0], [0, 0, 1], atol=1e-6)
