@@ -1,35 +1,51 @@
 #!/usr/bin/env python3
 """Throughput of the render path on MI355X: path-samples per second.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): sdf/example.sdf at 1920x1080, aa_steps = 32 (1024 samples
-per pixel on the reference's regular sub-pixel grid), max_ray_bounces = 5.  One step = one
-complete Renderer::render of that image: every rank renders ALL pixels for its slice of the
-1024 per-pixel samples into its own fp32 accumulation buffer, the buffers are summed onto
-rank 0 with one RCCL reduce, rank 0 resolves (average, tone map, 8-bit rows).  The scene is
-resident in HBM before the timed region starts; the image stays on the device.
+With N > 1 and no WORLD_SIZE in the environment the script starts itself N times through
+torch.distributed.run (one rank per GPU, RCCL) before anything touches a GPU; a launcher that
+already set RANK / WORLD_SIZE is used as is.
+
+Workload (BASELINE.json configs[2], the scene of the north star): cornell.sdf with the
+buster_sword.obj triangle mesh (16 008 triangles) at 1920x1080, aa_steps = 32 (1024 samples per
+pixel on the reference's regular sub-pixel grid), max_ray_bounces = 5.  One step = one complete
+Renderer::render of that image: every rank renders ALL pixels for its slice of the 1024
+per-pixel samples into its own fp32 accumulation buffer, the buffers are summed onto rank 0
+with one RCCL reduce, rank 0 resolves (average, tone map, 8-bit rows).  The scene is resident in
+HBM before the timed region starts; the image stays on the device.  configs[1] (example.sdf,
+same size) is rendered once after the timed steps and reported under "also".
 
 The JSON line also carries
-  roofline      the dominant kernel - the one with the largest share of the step's time: the
-                depth-0 closest-hit kernel k_trace<true> of the staged pipeline (or the depth-0
-                k_bounce<true> with --pipeline fused): algorithmic bytes per launch / its
-                average launch duration from HIP events recorded on the launch stream during
-                the timed steps, against 8 TB/s.  Algorithmic bytes follow the per-ray model
-                (ray record 48 B written once, read by intersect, read by shade; hit record
-                16 B written, read; 24 B accumulator update per shaded hit): the closest-hit
-                kernel's share is 48 + 16 B per ray it handles, the fused kernel's 176 B per
-                ray segment + 24 B per hit.  `traffic` is the kernel's HBM bytes per launch
-                from the FETCH_SIZE / WRITE_SIZE counter passes kept under profiles/ (taken
-                with scripts/pmc.sh on this same workload), or null when no such file is there;
-  cpu_baseline  the CPU oracle (oracle/cpu_ref.cpp, the bit-exact restatement of the
-                reference renderer) timed on this box's host cores on a bounded sample of
-                the same workload (same scene and resolution, fewer samples per pixel).
+  roofline      for the dominant kernel = the kernel symbol with the largest summed device time
+                inside the timed steps (HIP events recorded around every launch on the launch
+                stream): `achieved` = its ALGORITHMIC bytes / its time, against 8 TB/s.  The
+                algorithmic bytes follow the per-ray model (ray record 48 B: written by the
+                kernel that emits it, read by the closest-hit kernel, read by the shading kernel;
+                hit record 16 B written by the closest-hit kernel, read by the shading kernel;
+                24 B accumulator update per shaded hit or lit shadow ray), each kernel credited
+                only with the records it really moves: the depth-0 closest-hit kernel generates
+                its rays in registers and gets the hit records alone.  `traffic` = HBM bytes
+                per launch of that kernel from the committed FETCH_SIZE / WRITE_SIZE counter
+                passes (profiles/*_hbm_traffic.json) when they were taken on this workload,
+                else null.  `valu` = the same kernel against the vector fp32 peak, with flops
+                = 30 per slab test + 52 per triangle test + 37 per sphere test + 30 per box
+                test + 33 per ray transform (+ 140 per shaded hit in the shading kernels), the
+                tests counted by the kernels' counting twins in one extra, untimed step.
+                `kernels` lists every kernel symbol the same way;
+  cpu_baseline  the CPU oracle (oracle/cpu_ref.cpp, the bit-exact restatement of the reference
+                renderer) timed on this box's host cores on a bounded sample of the same
+                workload (same scene and resolution, fewer samples per pixel); when the real
+                reference (oracle/_ref/libref.so, its unmodified sources compiled in the build
+                container) came along, it is timed the same way and is the figure reported
+                (kind "reference", with the restatement's figure beside it as port_value).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,8 +54,9 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E
 VALU_PEAK_TFLOPS = 157.3    # vector fp32, FMA counted as 2
-BYTES_PER_RAY = 176         # ray record written + read by intersect + read by shade (3 x 48) + hit record written + read (2 x 16)
-BYTES_PER_HIT = 24          # float3 accumulator read-modify-write
+RAY_B, HIT_B, ACC_B = 48, 16, 24   # the per-ray model: ray record, hit record, accumulator read-modify-write
+BYTES_PER_RAY = 3 * RAY_B + 2 * HIT_B
+FLOPS = {"slab": 30, "tri": 52, "sphere": 37, "box": 30, "xform": 33, "shade": 140}
 
 
 def parse():
@@ -47,19 +64,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="example.sdf")
+    ap.add_argument("--scene", default="cornell_buster.sdf")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=32)
     ap.add_argument("--bounces", type=int, default=5)
-    ap.add_argument("--queue-gib", type=float, default=96.0, help="ray queue memory per GPU; larger queues mean fewer, larger launches")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration; 0 skips it")
-    ap.add_argument("--cpu-kind", choices=["port", "reference"], default="port")
+    ap.add_argument("--queue-gib", type=float, default=0.0, help="ray queue memory per GPU; 0 = the library's default (a third of the free memory, at most 96 GiB)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration; 0 skips it")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel launches with HIP events")
+    ap.add_argument("--no-census", action="store_true", help="skip the extra, untimed step that counts the tests")
+    ap.add_argument("--no-also", action="store_true", help="skip the single untimed-in-value render of configs[1]")
     ap.add_argument("--pipeline", choices=["default", "fused", "staged"], default="default")
+    ap.add_argument("--lib", default=None, help="another build of libptx.so to measure")
     ap.add_argument("--save-ppm", default=None)
     ap.add_argument("--verify", action="store_true", help="rank 0 also renders all samples alone and reports the max abs difference")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks of this script (before any GPU call) and pass their output on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(args, scene_path):
@@ -68,50 +99,129 @@ def cpu_baseline(args, scene_path):
     import oracle_lib
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     threads = max(1, min(threads, os.cpu_count() or 1))
-    if args.cpu_kind == "reference" and oracle_lib.Reference.available():
-        lib, kind = oracle_lib.Reference(), "reference"
-        threads = os.cpu_count() or 1  # the reference spawns hardware_concurrency() threads (framework/renderer.cpp:39)
-    else:
-        lib, kind = oracle_lib.Port(), "port"
-    s = lib.load(scene_path)
     w, h, nb = args.width, args.height, args.bounces
-    probe = lib.render(s, w, h, 1, nb, threads=threads)
-    rate = w * h / max(probe["seconds"], 1e-6)
-    aa = max(1, min(args.aa, int((args.cpu_seconds * rate / (w * h)) ** 0.5)))
-    r = lib.render(s, w, h, aa, nb, threads=threads)
-    samples = w * h * aa * aa
-    return {"value": samples / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
-            "sample": f"{args.scene} {w}x{h}, aa_steps={aa} ({aa * aa} of {args.aa * args.aa} spp), {nb} bounces, {r['seconds']:.1f} s"}
+
+    def timed(lib, seconds, **kw):
+        """about `seconds` of rendering: full resolution at reduced aa_steps when the cores manage
+        that, otherwise the same view at a reduced resolution and aa_steps = 1"""
+        s = lib.load(scene_path)
+        pw, ph = max(16, w // 4), max(16, h // 4)
+        probe = lib.render(s, pw, ph, 1, nb, **kw)
+        target = seconds * pw * ph / max(probe["seconds"], 1e-6)   # samples that fit the time
+        if target >= w * h:
+            rw, rh, aa = w, h, max(1, min(args.aa, int((target / (w * h)) ** 0.5)))
+        else:
+            f = max((target / (w * h)) ** 0.5, 0.05)
+            rw, rh, aa = max(16, int(w * f)), max(16, int(h * f)), 1
+        r = lib.render(s, rw, rh, aa, nb, **kw)
+        return rw * rh * aa * aa / r["seconds"] / 1e6, f"{rw}x{rh}, aa_steps={aa}", r["seconds"]
+
+    v, what, sec = timed(oracle_lib.Port(), args.cpu_seconds, threads=threads)
+    port = {"value": v, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{args.scene} {what} (of {w}x{h}, aa_steps={args.aa}), {nb} bounces, {sec:.1f} s"}
+    if not oracle_lib.Reference.available():
+        return port
+    # The real reference came along as a binary: it is the baseline, the restatement is quoted beside it.
+    # It prints its own timing line to the C stdout; keep this script's stdout to the one JSON line.
+    import ctypes
+    sys.stdout.flush()
+    saved, null = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null, 1)
+    try:
+        rv, rwhat, rsec = timed(oracle_lib.Reference(), args.cpu_seconds)
+        err = None
+    except Exception as e:  # the baseline must never take the bench line down
+        err = str(e)[:200]
+    finally:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(null)
+    if err is not None:
+        port["reference_error"] = err
+        return port
+    # the reference spawns hardware_concurrency() threads (framework/renderer.cpp:39)
+    return {"value": rv, "unit": "Msamples/s", "cores": os.cpu_count(), "kind": "reference",
+            "sample": f"{args.scene} {rwhat} (of {w}x{h}, aa_steps={args.aa}), {nb} bounces, {rsec:.1f} s incl. its ASCII PPM write",
+            "cpu_share": os.environ.get("OMP_NUM_THREADS"), "port_value": port["value"], "port_cores": threads, "port_sample": port["sample"]}
 
 
-def measured_traffic(args, kernel, launches):
+def measured_traffic(args, queue_gib, kernel):
     """HBM bytes per launch of `kernel` from the committed counter passes (the newest
     profiles/*_hbm_traffic.json, written by scripts/pmc_summary.py --traffic), if they were taken
     on this workload: same scene, size, spp, bounces and queue memory, hence the same launches."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_hbm_traffic.json")))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
-        return None
-    w = t.get("_workload", {})
-    if [w.get(k) for k in ("scene", "width", "height", "aa", "bounces", "queue_gib")] != [args.scene, args.width, args.height, args.aa, args.bounces, args.queue_gib]:
-        return None
-    k = t.get(kernel)
-    if not k or "hbm_bytes_per_launch" not in k:
-        return None
-    return k["hbm_bytes_per_launch"]
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = t.get("_workload", {})
+        if [w.get(k) for k in ("scene", "width", "height", "aa", "bounces")] != [args.scene, args.width, args.height, args.aa, args.bounces]:
+            continue
+        if abs(float(w.get("queue_gib", -1)) - queue_gib) > 0.5:
+            continue
+        k = t.get(kernel)
+        if k and "hbm_bytes_per_launch" in k:
+            return k["hbm_bytes_per_launch"]
+    return None
+
+
+def kernel_table(stats, census, nb, staged):
+    """Per kernel symbol: device time and launches inside the last timed step, algorithmic bytes
+    by the per-ray model, flops from the census counts (None without a census)."""
+    kms, kln = stats["kernel_ms"], stats["kernel_launches"]
+    rays, hits, shadow = stats["per_depth_rays"], stats["per_depth_hits"], stats["per_depth_shadow"]
+    D = range(nb + 1)
+
+    def flops(tests, depths):
+        if census is None:
+            return None
+        t = [sum(census[tests][d][k] for d in depths) for k in range(5)]
+        return FLOPS["slab"] * t[0] + FLOPS["tri"] * t[1] + FLOPS["sphere"] * t[2] + FLOPS["box"] * t[3] + FLOPS["xform"] * t[4]
+
+    deep = [d for d in D if d >= 1]
+    out = {}
+    if not staged:
+        for name, ds in (("k_bounce<true>", [0]), ("k_bounce<false>", deep)):
+            n = sum(kln[0][d] for d in ds)
+            if n:
+                out[name] = {"ms": sum(kms[0][d] for d in ds), "launches": n,
+                             "bytes": sum(BYTES_PER_RAY * (rays[d] + shadow[d]) + ACC_B * hits[d] for d in ds) - (RAY_B * 2 * rays[0] if ds == [0] else 0),
+                             "flops": None}
+        return out
+    children = [rays[d + 1] if d + 1 <= nb else 0 for d in D]   # rays depth d's shading emitted
+    rows = (
+        # closest hit: the ray read from its queue (not at depth 0: generated in registers) + the hit record written
+        ("k_trace<true>", 0, [0], lambda d: HIT_B * hits[d], "trace_tests", 0),
+        ("k_trace<false>", 0, deep, lambda d: RAY_B * rays[d] + HIT_B * hits[d], "trace_tests", 0),
+        # shading: hit record read, the ray read (not at depth 0: regenerated), accumulator, child and shadow rays written
+        ("k_shade<true>", 1, [0], lambda d: (HIT_B + ACC_B) * hits[d] + RAY_B * (children[d] + shadow[d]), None, FLOPS["shade"]),
+        ("k_shade<false>", 1, deep, lambda d: (HIT_B + ACC_B + RAY_B) * hits[d] + RAY_B * (children[d] + shadow[d]), None, FLOPS["shade"]),
+        # shadow rays: the record read, the accumulator updated (counted for every ray: the model does not know which are lit)
+        ("k_shadow", 2, list(D), lambda d: (RAY_B + ACC_B) * shadow[d], "shadow_tests", 0),
+    )
+    for name, kind, ds, bytes_of, tests, per_hit in rows:
+        n = sum(kln[kind][d] for d in ds)
+        if not n:
+            continue
+        f = flops(tests, ds) if tests else (per_hit * sum(hits[d] for d in ds) if census is not None else None)
+        out[name] = {"ms": sum(kms[kind][d] for d in ds), "launches": n, "bytes": sum(bytes_of(d) for d in ds), "flops": f}
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
     pt = importlib.import_module("path-tracer_amd")
     ptdist = importlib.import_module("path-tracer_amd.dist")
+    if args.lib:
+        pt.set_library(args.lib)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,25 +237,18 @@ def main():
     device_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    local_rank = device_index
 
     scene_path = os.path.join(pt.SDF_DIR, args.scene)
     host = pt.HostScene(scene_path)
-    # the queue block is the only large allocation; if the device cannot give that much (other
-    # tenants), take half, and so on: smaller queues only mean more, smaller launches
-    queue_gib = args.queue_gib
-    while True:
-        try:
-            ds = pt.DeviceScene(host, local_rank, int(queue_gib * (1 << 30)))
-            break
-        except pt.PtxError as e:
-            if "NOMEM" not in str(e) or queue_gib <= 1.0:
-                raise
-            queue_gib /= 2
-            print(f"note: rank {rank}: queue allocation failed, retrying with {queue_gib} GiB", file=sys.stderr)
-    args.queue_gib = queue_gib
+    free_before = torch.cuda.mem_get_info()[0]
+    ranks_here = max(1, world // max(torch.cuda.device_count(), 1)) if backend != "nccl" else 1
+    queue_bytes = int(args.queue_gib * (1 << 30))
+    if ranks_here > 1 and queue_bytes == 0:
+        queue_bytes = free_before // (4 * ranks_here)   # rehearsal: several ranks share this card
+    ds = pt.DeviceScene(host, device_index, queue_bytes)
+    queue_gib = round((free_before - torch.cuda.mem_get_info()[0]) / (1 << 30), 1)   # what the library took
     profile = not args.no_profile
-    ds.set_profiling(profile)
+    ds.set_profiling(1 if profile else 0)
 
     w, h, aa, nb = args.width, args.height, args.aa, args.bounces
     spp = aa * aa
@@ -190,7 +293,7 @@ def main():
         out = {
             "metric": "path samples/sec", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (scene file shipped with the reference; regular sample grid, no RNG)",
+            "dtype": "f32", "data": "synthetic (scene files shipped with the reference; regular sample grid, no RNG)",
             "config": {"workload": f"{args.scene} {w}x{h}, aa_steps={aa} ({spp} spp), max_ray_bounces={nb}", "queue_gib": queue_gib,
                        "samples_per_step": samples_per_step, "parallelism": f"sample-range x{world}, one RCCL sum-reduce per image"},
         }
@@ -200,30 +303,51 @@ def main():
         my_samples = stats["samples"]
         out["work"] = {"rays_per_sample": R / my_samples, "shaded_hits_per_sample": H / my_samples,
                        "trace_rays_per_sample": stats["trace_rays"] / my_samples, "shadow_rays_per_sample": stats["shadow_rays"] / my_samples,
-                       "algorithmic_bytes_per_sample": (BYTES_PER_RAY * R + BYTES_PER_HIT * H) / my_samples,
+                       "algorithmic_bytes_per_sample": (BYTES_PER_RAY * R + ACC_B * H) / my_samples,
                        "Mrays/s": R * world * args.steps / elapsed / 1e6 if world == 1 else None,
                        "kernel_launches_per_step": stats["launches"]}
-        kms, kln = stats["kernel_ms"], stats["kernel_launches"]
+        kln = stats["kernel_launches"]
         if profile and kln[0][0]:
-            # dominant kernel = the depth-0 launch of kernel kind 0: the fused bounce kernel, or
-            # (staged pipeline) the closest-hit kernel.  Its algorithmic bytes: fused = every ray
-            # segment it handles (primary + its shadow rays) and every hit it shades; staged
-            # closest-hit kernel = its share of a ray segment: ray record read + hit record written.
-            n0, ms0 = kln[0][0], kms[0][0]
             staged = kln[1][0] > 0
-            rays0, shadow0, hits0 = stats["per_depth_rays"][0], stats["per_depth_shadow"][0], stats["per_depth_hits"][0]
-            if staged:
-                name = "k_trace<true, false> (depth 0: ray generation + closest hit -> hit records)"
-                bytes0 = (48 + 16) * rays0
-            else:
-                name = "k_bounce<true> (depth 0: ray generation + closest hit + shading + shadow + emit + accumulate)"
-                bytes0 = BYTES_PER_RAY * (rays0 + shadow0) + BYTES_PER_HIT * hits0
-            achieved = bytes0 / (ms0 * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, "k_trace<true, false>" if staged else "k_bounce<true, true>", n0),
-                               "launches": n0, "avg_launch_ms": ms0 / n0, "algorithmic_bytes_per_launch": bytes0 / n0}
-            tot_ms = sum(sum(r) for r in kms)
-            tot_bytes = BYTES_PER_RAY * R + BYTES_PER_HIT * H
+            census = None
+            if not args.no_census and staged:
+                # one more step, untimed, with the counting twins of the traversal kernels
+                ds.set_profiling(2)
+                c = ds.render_accumulate(rp, torch.zeros_like(accum).data_ptr(), stream, check_overflow=True, want_stats=True)
+                ds.set_profiling(1)
+                census = {"trace_tests": c["trace_tests"], "shadow_tests": c["shadow_tests"]}
+                tr = [sum(c["trace_tests"][d][k] for d in range(nb + 1)) for k in range(5)]
+                sh = [sum(c["shadow_tests"][d][k] for d in range(nb + 1)) for k in range(5)]
+                names = ("slab", "triangle", "sphere", "box", "transform")
+                out["work"]["tests_per_trace_ray"] = {n: v / max(c["trace_rays"], 1) for n, v in zip(names, tr)}
+                out["work"]["tests_per_shadow_ray"] = {n: v / max(c["shadow_rays"], 1) for n, v in zip(names, sh)}
+            table = kernel_table(stats, census, nb, staged)
+            tot_ms = sum(k["ms"] for k in table.values())
+            kernels = {}
+            for name, k in table.items():
+                sec = k["ms"] * 1e-3
+                gbs = k["bytes"] / sec / 1e9
+                row = {"ms_per_step": round(k["ms"], 3), "share": round(k["ms"] / tot_ms, 4), "launches": k["launches"],
+                       "algorithmic_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+                if k["flops"] is not None:
+                    row["TFLOPs"] = round(k["flops"] / sec / 1e12, 2)
+                    row["valu_frac"] = round(k["flops"] / sec / 1e12 / VALU_PEAK_TFLOPS, 4)
+                kernels[name] = row
+            dom = max(table, key=lambda n: table[n]["ms"])
+            k = table[dom]
+            achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            symbol = {"k_trace<true>": "k_trace<true, %s, NoCount>", "k_trace<false>": "k_trace<false, %s, NoCount>",
+                      "k_shadow": "k_shadow<%s, NoCount>"}.get(dom)
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, queue_gib, dom),
+                               "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
+                               "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
+                               "valu": None if k["flops"] is None else {
+                                   "achieved": k["flops"] / (k["ms"] * 1e-3) / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": k["flops"] / (k["ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS},
+                               "symbol_pattern": symbol}
+            out["kernels"] = kernels
+            kms = stats["kernel_ms"]
             out["kernel_time"] = {"pipeline": "staged" if staged else "fused",
                                   "closest_hit_or_fused_ms_per_depth": [round(x, 3) for x in kms[0][: nb + 1]],
                                   "shade_ms_per_depth": [round(x, 3) for x in kms[1][: nb + 1]],
@@ -231,13 +355,10 @@ def main():
                                   "per_depth_rays": stats["per_depth_rays"][: nb + 1],
                                   "per_depth_hits": stats["per_depth_hits"][: nb + 1],
                                   "per_depth_shadow_rays": stats["per_depth_shadow"][: nb + 1],
-                                  "all_launches_ms": tot_ms, "all_launches_algorithmic_GBs": tot_bytes / (tot_ms * 1e-3) / 1e9}
+                                  "all_launches_ms": tot_ms,
+                                  "all_launches_algorithmic_GBs": (BYTES_PER_RAY * R + ACC_B * H) / (tot_ms * 1e-3) / 1e9}
         else:
             out["roofline"] = None
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args, scene_path)
-        else:
-            out["cpu_baseline"] = None
         if args.verify:
             # the summed image of all ranks against one rank rendering every sample alone
             acc1 = torch.zeros_like(accum)
@@ -248,6 +369,27 @@ def main():
             out["verify_max_abs_vs_single_rank"] = float((col1 - color).abs().max().item())
         if args.save_ppm:
             pt.write_ppm(args.save_ppm, rgb.cpu().numpy().reshape(h, w, 3))
+        if world == 1 and not args.no_also and args.scene != "example.sdf":
+            # BASELINE configs[1] at its full size, one image through the same calls
+            hs2 = pt.HostScene(os.path.join(pt.SDF_DIR, "example.sdf"))
+            ds.close()
+            ds2 = pt.DeviceScene(hs2, device_index, queue_bytes)
+            rp2 = pt.render_params(w, h, aa, nb)
+            for k in range(2):
+                accum.zero_()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ds2.render_accumulate(rp2, accum.data_ptr(), stream, check_overflow=True)
+                ds2.resolve(accum.data_ptr(), w, h, spp, color.data_ptr(), rgb.data_ptr(), stream)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+            out["also"] = {f"example.sdf {w}x{h}, aa_steps={aa}, max_ray_bounces={nb}": {"Msamples/s": samples_per_step / dt / 1e6, "ms_per_step": dt * 1e3}}
+            ds2.close()
+            ds = None
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args, scene_path)
+        else:
+            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

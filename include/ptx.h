@@ -169,6 +169,15 @@ typedef struct PtxStats {
 	 * 2 = shadow kernel (kinds 1 and 2 only in the staged pipeline) */
 	double kernel_ms[3][16];
 	uint64_t kernel_launches[3][16];
+	/* filled only at profiling level 2 (tests_counted = 1): what the closest-hit kernel and the
+	 * shadow kernel tested, per ray-tree depth, counted per ray (lane) that ran the test:
+	 * [depth][0] slab tests (bounding boxes: root and mesh bounds_, the filter in front of a
+	 * root shape, 2 per BVH node visited)  [1] triangle tests  [2] sphere tests  [3] box tests
+	 * [4] ray transforms into a shape's or mesh's own space.  These are the Box / Triangle /
+	 * Sphere::intersect and transform_ray calls of the reference (framework/composite.cpp:78-96). */
+	uint64_t trace_tests[16][5];
+	uint64_t shadow_tests[16][5];
+	uint64_t tests_counted;
 } PtxStats;
 
 const char* ptx_last_error(void);
@@ -179,8 +188,9 @@ int ptx_device_count(void);
 
 /*
  * Validates and uploads a scene to `device`, builds the per-frame BVHs and allocates the
- * ray queues.  queue_bytes = HBM budget for the ray queues (0 = default 4 GiB; at least
- * 96 MiB is taken; more memory means fewer, larger kernel launches, never different results).
+ * ray queues.  queue_bytes = HBM budget for the ray queues (0 = a third of the memory the
+ * device has free at this moment, at most 96 GiB; at least 96 MiB is taken; more memory
+ * means fewer, larger kernel launches, never different results).
  * Replaces the per-thread Scene copies of framework/renderer.cpp:48.
  * A PtxScene owns its queues and counters: use it from one thread (one render) at a time;
  * different scenes are independent.  ptx_last_error() is per thread.
@@ -194,8 +204,11 @@ void ptx_scene_destroy(PtxScene* scene);
  * here).  All device work goes to `stream`.  The call waits on that stream once per chunk of
  * primary samples when the scene spawns secondary rays (it reads the queue counters; a chunk
  * is as many samples as the queue memory is certain to hold the ray tree of), and once at the
- * end for the overflow flag and the statistics when `stats` is non-NULL or check_overflow is
- * non-zero.  Rays are never dropped silently: PTX_ERR_OVERFLOW if a queue ever filled up.
+ * end for the statistics when `stats` is non-NULL or check_overflow is non-zero.
+ * Launches are sized so that no queue can fill up whatever the materials do; the kernels still
+ * flag a record that would not fit, and with check_overflow != 0 (or stats) the call reads that
+ * flag at its end and returns PTX_ERR_OVERFLOW if it was ever raised (check_overflow = 0 and
+ * stats = NULL skips that read and the wait it needs).
  */
 PtxStatus ptx_render_accumulate(PtxScene* scene, const PtxRenderParams* params, float* d_accum, void* stream,
                                 int check_overflow, PtxStats* stats);
@@ -247,10 +260,12 @@ PtxStatus ptx_write_ppm_binary(const char* path, const uint8_t* rgb8, uint32_t w
 PtxStatus ptx_write_pfm(const char* path, const float* color, uint32_t width, uint32_t height);
 
 /*
- * Profiling on: ptx_render_accumulate brackets every bounce-kernel launch with a pair of
+ * Profiling level 1: ptx_render_accumulate brackets every bounce-kernel launch with a pair of
  * HIP events on the caller's stream and reports per-depth kernel time in PtxStats (which
- * then must be requested).  Off by default.  No counterpart in the reference, whose only
- * timing is a wall clock around render() (framework/renderer.cpp:43,54-56).
+ * then must be requested).  Level 2: in addition the traversal kernels run as their counting
+ * twins (same code plus one counter per kind of test; slower by the counting) and PtxStats
+ * carries trace_tests / shadow_tests.  0 = off, the default.  No counterpart in the
+ * reference, whose only timing is a wall clock around render() (framework/renderer.cpp:43,54-56).
  */
 PtxStatus ptx_scene_set_profiling(PtxScene* scene, int enable);
 

@@ -73,16 +73,28 @@ class PtxRenderParams(C.Structure):
 class PtxStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("trace_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("launches", C.c_uint64), ("per_depth_rays", C.c_uint64 * 16), ("per_depth_shadow", C.c_uint64 * 16),
-                ("per_depth_hits", C.c_uint64 * 16), ("kernel_ms", (C.c_double * 16) * 3), ("kernel_launches", (C.c_uint64 * 16) * 3)]
+                ("per_depth_hits", C.c_uint64 * 16), ("kernel_ms", (C.c_double * 16) * 3), ("kernel_launches", (C.c_uint64 * 16) * 3),
+                ("trace_tests", (C.c_uint64 * 5) * 16), ("shadow_tests", (C.c_uint64 * 5) * 16), ("tests_counted", C.c_uint64)]
 
     def as_dict(self):
         return dict(samples=self.samples, trace_rays=self.trace_rays, shadow_rays=self.shadow_rays, shaded_hits=self.shaded_hits,
                     launches=self.launches, per_depth_rays=list(self.per_depth_rays), per_depth_shadow=list(self.per_depth_shadow),
                     per_depth_hits=list(self.per_depth_hits), kernel_ms=[list(r) for r in self.kernel_ms],
-                    kernel_launches=[list(r) for r in self.kernel_launches])
+                    kernel_launches=[list(r) for r in self.kernel_launches], trace_tests=[list(r) for r in self.trace_tests],
+                    shadow_tests=[list(r) for r in self.shadow_tests], tests_counted=bool(self.tests_counted))
 
 
 _libs = {}
+_ptx_path = None
+
+
+def set_library(path):
+    """Load the render library from `path` instead of the in-tree libptx.so (for comparing two
+    builds with bench.py --lib); must be called before the first use."""
+    global _ptx_path
+    if "ptx" in _libs:
+        raise RuntimeError("the render library is already loaded")
+    _ptx_path = os.path.abspath(path)
 
 
 def _load(name):
@@ -95,7 +107,14 @@ def _load(name):
 
 
 def ptx_lib():
-    L = _load(os.environ.get("PTX_LIB", "libptx.so"))
+    if "ptx" not in _libs:
+        if _ptx_path is not None:
+            if not os.path.exists(_ptx_path):
+                raise FileNotFoundError(_ptx_path)
+            _libs["ptx"] = C.CDLL(_ptx_path, mode=C.RTLD_GLOBAL)
+        else:
+            _libs["ptx"] = _load("libptx.so")
+    L = _libs["ptx"]
     if getattr(L, "_typed", False):
         return L
     vp = C.c_void_p
@@ -230,8 +249,9 @@ class DeviceScene:
         except Exception:
             pass
 
-    def set_profiling(self, enable=True):
-        _check(self.L.ptx_scene_set_profiling(self.handle, int(enable)))
+    def set_profiling(self, level=1):
+        """0 off, 1 HIP events around every launch, 2 events + test counting (slower kernels)"""
+        _check(self.L.ptx_scene_set_profiling(self.handle, int(level)))
 
     def info(self):
         a, b, c, d, e = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()

@@ -80,22 +80,31 @@ bool is_identity(const float* m) {
 
 }  // namespace
 
+// Device memory a render works in (everything besides the scene tables, the inputs and the
+// accumulation buffer): the scene's own block, or one the caller of the driver supplies.
+struct WorkMem {
+	float4* qmem = nullptr;        // cut per render into ray queues, a shadow queue and a hit list
+	uint64_t qslots = 0;           // its size in 48-byte slots
+	unsigned* counts = nullptr;    // tail counters: per depth 64 sub-queue tails, 128 B apart, for rays, shadow rays and hits (kCountBytes)
+	Counters* counters = nullptr;  // kCounterBytes
+	unsigned long long* stat = nullptr;  // kStatBytes
+};
+constexpr unsigned kGridRounds = 4;  // a persistent grid holds this many times the blocks the device keeps resident (2..6 measured flat)
+
 struct PtxScene {
 	int device = 0;
 	DevScene dev{};
 	PtxCamera camera{};
 	std::vector<void*> allocs;
-	float4* qmem = nullptr;  // one block of work memory, cut per render into ray queues, a shadow queue and a hit list
-	uint64_t qrays = 0;      // its size in 48-byte slots
-	unsigned* d_counts = nullptr;  // tail counters: per depth 64 sub-queue tails, 128 B apart, for rays, shadow rays and hits
-	Counters* d_counters = nullptr;
-	unsigned long long* d_stat = nullptr;
+	WorkMem work;
+	std::vector<unsigned> tails;   // host copy of the tail counters a render reads back (sized once, at creation)
+	Counters host_counters{};
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
 	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
-	unsigned n_cus = 0, grid_rounds = 4;
+	unsigned n_cus = 0;
 	std::map<const void*, unsigned> resident_blocks;  // per kernel: blocks the device keeps resident at once
-	bool profiling = false;
+	int profiling = 0;       // 0 off, 1 events around every launch, 2 events + the counting twins of the traversal kernels
 	std::vector<hipEvent_t> events;      // pairs, reused from call to call
 	std::vector<unsigned> event_tag;     // kernel kind and depth of pair k
 	int n_prims = 0, n_frames = 0, n_nodes = 0, max_depth = 0, grid = 0;
@@ -237,7 +246,6 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	sc->n_frames = D->n_frames;
 	sc->grid = prop.multiProcessorCount * 8;
 	sc->n_cus = (unsigned) prop.multiProcessorCount;
-	if (const char* e = std::getenv("PTX_GRID_ROUNDS")) sc->grid_rounds = (unsigned) std::max(1, std::atoi(e));
 
 	// ---- materials, lights
 	std::vector<float4> mats((size_t) D->n_materials * 4);
@@ -401,9 +409,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	// ---- many leaves in frame 0: a BVH of their own over the padded bounding boxes (the filter
 	// boxes), the four per-leaf tables put into its leaf order.  Up to kRootBvhMin leaves the
 	// wave-uniform list with its scalar loads is the faster way.
-	int root_bvh_min = kRootBvhMin;
-	if (const char* e = std::getenv("PTX_ROOT_BVH_MIN")) root_bvh_min = std::max(0, std::atoi(e));
-	if ((int) root_prims.size() > root_bvh_min) {
+	if ((int) root_prims.size() > kRootBvhMin) {
 		std::vector<ptx::Aabb> boxes(root_prims.size());
 		bool finite = true;
 		for (size_t k = 0; k < boxes.size(); ++k) {
@@ -481,12 +487,16 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(S.root_max, D->frames[0].bounds_max, sizeof S.root_max);
 
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
-	if (queue_bytes == 0) queue_bytes = 4ull << 30;
+	if (queue_bytes == 0) {  // a third of what the device has free now, at most 96 GiB (more was measured to add nothing)
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		queue_bytes = std::min<uint64_t>(free_b / 3, 96ull << 30);
+	}
 	uint64_t cap = queue_bytes / 48;
 	cap = std::min<uint64_t>(cap, 1ull << 33);  // 384 GiB: above any device; each queue is limited on its own (64 sub-queues of at most 2^25 records)
 	cap = std::max<uint64_t>(cap, 1ull << 21);  // 96 MiB: enough for one sub-queued queue per depth at the deepest tree allowed
 	cap &= ~127ull;
-	sc->qrays = cap;
+	sc->work.qslots = cap;
 	{
 		void* p = nullptr;
 		hipError_t e = hipMalloc(&p, cap * 48);
@@ -496,21 +506,21 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		}
 		sc->allocs.push_back(p);
 		sc->device_bytes += cap * 48;
-		sc->qmem = static_cast<float4*>(p);
+		sc->work.qmem = static_cast<float4*>(p);
 	}
 	{
 		void* p = nullptr;
 		if (hipMalloc(&p, kCountBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
-		sc->d_counts = static_cast<unsigned*>(p);
-		if (hipMalloc(&p, 1024) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
+		sc->work.counts = static_cast<unsigned*>(p);
+		if (hipMalloc(&p, kCounterBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
-		sc->d_counters = static_cast<Counters*>(p);
+		sc->work.counters = static_cast<Counters*>(p);
 		if (hipMalloc(&p, kStatBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
-		sc->d_stat = static_cast<unsigned long long*>(p);
-		static_assert(sizeof(Counters) <= 1024, "counter block");
+		sc->work.stat = static_cast<unsigned long long*>(p);
 	}
+	sc->tails.assign((size_t) (kMaxBounces + 2) * kCountsPerDepth, 0u);
 	*out = sc.release();
 	return PTX_OK;
 }
@@ -524,7 +534,7 @@ void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx
 
 PtxStatus ptx_scene_set_profiling(PtxScene* scene, int enable) {
 	if (!scene) return fail(PTX_ERR_INVALID, "scene is NULL");
-	scene->profiling = enable != 0;
+	scene->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
 	return PTX_OK;
 }
 
@@ -547,20 +557,20 @@ PtxStatus ptx_scene_info(const PtxScene* sc, int32_t* n_frames, int32_t* n_prims
 	return PTX_OK;
 }
 
-PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* d_accum, void* stream_, int check_overflow,
-                                PtxStats* stats) {
-	if (!sc || !d_accum) return fail(PTX_ERR_INVALID, "scene/d_accum is NULL");
-	PtxStatus st = check_params(rp);
-	if (st != PTX_OK) return st;
-	hipStream_t stream = static_cast<hipStream_t>(stream_);
-	HIP_TRY(hipSetDevice(sc->device));
+}  // extern "C"
 
+namespace {
+
+// One render into d_accum with the work memory `M` (the scene's own block, or any other that
+// holds the same parts).  Calls no allocating routine unless profiling has to create events.
+PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParams* rp, float* d_accum, hipStream_t stream, int check_overflow,
+                            PtxStats* stats) {
 	BounceArgs A{};
 	A.S = sc->dev;
 	camera_basis(sc->camera, *rp, A.cam);
 	A.accum = d_accum;
-	A.counters = sc->d_counters;
-	A.stat = sc->d_stat;
+	A.counters = M.counters;
+	A.stat = M.stat;
 	const unsigned ns = rp->sample_end - rp->sample_begin;
 	A.ns = ns;
 	A.inv_ns = 1.0 / ns;
@@ -568,10 +578,11 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	const uint64_t total = (uint64_t) rp->width * rp->height * ns;
 	const unsigned max_depth = sc->bouncing ? rp->max_ray_bounces : 0;  // no material spawns rays: depth 0 only
 
-	HIP_TRY(hipMemsetAsync(sc->d_counters, 0, 1024, stream));
-	HIP_TRY(hipMemsetAsync(sc->d_stat, 0, kStatBytes, stream));
+	HIP_TRY(hipMemsetAsync(M.counters, 0, kCounterBytes, stream));
+	HIP_TRY(hipMemsetAsync(M.stat, 0, kStatBytes, stream));
 	uint64_t launches = 0;
-	const bool prof = sc->profiling && stats;
+	const bool prof = sc->profiling > 0 && stats;
+	const bool count_tests = sc->profiling > 1 && stats;
 	const bool staged = rp->pipeline != PTX_PIPELINE_FUSED;  // the default is the staged pipeline (the faster one on the measured scenes)
 	sc->event_tag.clear();
 	// profiling: a pair of events around every launch; tag = kind * kMaxDepthSlots + depth slot
@@ -590,19 +601,19 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	};
 	auto queue_at = [&](uint64_t first_slot, uint64_t cap) {
 		RayQueue q;
-		q.a = sc->qmem + first_slot * 3;
+		q.a = M.qmem + first_slot * 3;
 		q.b = q.a + cap;
 		q.c = reinterpret_cast<float2*>(q.b + cap);
 		return q;
 	};
-	auto count_of = [&](unsigned depth) { return sc->d_counts + (size_t) depth * kCountsPerDepth; };
-	auto shadow_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (kMaxBounces + 2 + depth) * kCountsPerDepth; };
-	auto hit_count_of = [&](unsigned depth) { return sc->d_counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kCountsPerDepth; };
+	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * kCountsPerDepth; };
+	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * kCountsPerDepth; };
+	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kCountsPerDepth; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
 	const bool rb = sc->dev.root_bvh != 0;  // (the fused kernel has no such variant: it takes the leaves one by one)
 	// persistent grids: as many blocks as the kernel can keep resident on the device, times
-	// kGridRounds so that blocks which finish early are replaced; never more than `useful`
+	// grid_rounds so that blocks which finish early are replaced; never more than `useful`
 	auto grid_of = [&](auto kern, uint64_t useful) -> unsigned {
 		const void* key = reinterpret_cast<const void*>(kern);
 		auto it = sc->resident_blocks.find(key);
@@ -611,7 +622,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
 			it = sc->resident_blocks.emplace(key, (unsigned) per_cu * sc->n_cus).first;
 		}
-		return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(useful, (uint64_t) it->second * sc->grid_rounds));
+		return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(useful, (uint64_t) it->second * kGridRounds));
 	};
 	auto launch_depth = [&](unsigned d, uint64_t useful) -> PtxStatus {
 		if (!staged) {
@@ -627,7 +638,11 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		A.hit_count = hit_count_of(d);
 		HIP_TRY(tick(0, d, true));
 		{
-			auto kern = d == 0 ? (rb ? k_trace<true, true> : k_trace<true, false>) : (rb ? k_trace<false, true> : k_trace<false, false>);
+			auto pick = [&](auto counted) {
+				using TC = decltype(counted);
+				return d == 0 ? (rb ? k_trace<true, true, TC> : k_trace<true, false, TC>) : (rb ? k_trace<false, true, TC> : k_trace<false, false, TC>);
+			};
+			auto kern = count_tests ? pick(TestCount{}) : pick(NoCount{});
 			hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
 		}
 		HIP_TRY(tick(0, d, false));
@@ -637,7 +652,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
-			auto kern = rb ? k_shadow<true> : k_shadow<false>;
+			auto kern = count_tests ? (rb ? k_shadow<true, TestCount> : k_shadow<false, TestCount>) : (rb ? k_shadow<true, NoCount> : k_shadow<false, NoCount>);
 			hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(2, d, false));
 			launches += 1;
@@ -645,82 +660,75 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 		launches += 2;
 		return PTX_OK;
 	};
-	// most input rays a launch may take so that no sub-queue of its outputs can fill up: the
-	// sub-queue that gets the most steps gets ceil(steps / kNQ) of them, each at most
-	// 64 * (records per ray) records (children: 2 with a two-child material, else 1; shadow
-	// rays: one per light)
-	const unsigned per_step = sc->branching ? 128 : 64;
-	const unsigned per_step_shadow = 64 * (unsigned) std::max(sc->dev.n_lights, 1);
-	auto max_input = [&](uint64_t subcap) -> uint64_t {
-		uint64_t steps = subcap / per_step;
-		if (staged) steps = std::min<uint64_t>(steps, subcap / per_step_shadow);
-		return steps > 1 ? (steps - 1) * kNQ * 64 : 0;
-	};
+	// Sizing (see the note on queues in ptx_kernels.hpp): what a launch takes of sub-queue q of
+	// its input lands in sub-queue q of its outputs, at most `per_ray` records per input ray in
+	// any one output queue (children: 2 with a two-child material, else 1; shadow rays: one per
+	// light; hits: 1).  So a launch may take `take` = subcap / per_ray records of every
+	// sub-queue and nothing can overflow, whatever the materials do.
+	unsigned per_ray = sc->branching ? 2u : 1u;
+	if (staged) per_ray = std::max(per_ray, (unsigned) std::max(sc->dev.n_lights, 1));
 	// slots of one queue when the memory holds `queues` ray queues (+ shadow queue and hit
 	// records for the staged pipeline: 48 + 16 bytes more per slot)
 	auto slots_for = [&](unsigned queues) -> uint64_t {
-		uint64_t bytes = sc->qrays * 48;
+		uint64_t bytes = M.qslots * 48;
 		uint64_t per_slot = 48ull * queues + (staged ? 64 : 0);
 		return (bytes / per_slot) & ~(uint64_t) (kNQ * 64 - 1);
 	};
 	auto place_staged = [&](unsigned queues, uint64_t cap) {  // shadow queue and hit records behind the ray queues
 		A.shadow = queue_at((uint64_t) queues * cap, cap);
 		A.shadow_subcap = (unsigned) std::min<uint64_t>(cap / kNQ, 1u << 25);
-		A.hits = sc->qmem + ((uint64_t) queues + 1) * cap * 3;
+		A.hits = M.qmem + ((uint64_t) queues + 1) * cap * 3;
 		A.hit_subcap = (unsigned) std::min<uint64_t>(cap / kNQ, 1u << 25);
 	};
 
 	// Driving the ray tree through the queues: queue d (1..max_depth) holds the rays traced at
-	// depth d.  A launch takes at most `chunk` input rays, the number whose children (and
-	// shadow rays) are certain to fit the next queue whatever the materials do, so nothing can
-	// overflow.  Real scenes spawn far fewer children than that bound, so every depth of a
-	// primary chunk is first launched once, back to back, each launch reading its ray count on
-	// the device and taking min(count, chunk) rays; the host then reads the tail counters ONCE
-	// per primary chunk.  Only if some depth held more than `chunk` rays (deep trees of
-	// two-child materials) is its remainder traced, deepest depth first - the queues below a
-	// depth are free by then - chunk by chunk with the counts read back after every launch
-	// (depth-first over the chunks).
+	// depth d.  Every depth of a primary chunk is first launched once, back to back, each launch
+	// reading its ray counts on the device and taking at most `take` rays of every sub-queue;
+	// the host then reads the tail counters ONCE per primary chunk.  Only if some sub-queue of
+	// a depth held more than `take` rays (deep trees of two-child materials) is the remainder
+	// traced, deepest depth first - the queues below a depth are free by then - slice by slice
+	// with the counts read back after every launch (depth-first over the slices).
 	const unsigned nqueues = std::max(max_depth, 1u);
 	const uint64_t capd = slots_for(nqueues);
-	const unsigned subcap = (unsigned) std::min<uint64_t>(capd / kNQ, 1u << 25);  // 64 sub-queues of it stay below 2^32 rays
-	unsigned chunk = (unsigned) std::min<uint64_t>(max_input(subcap), 1u << 30);
-	if (max_depth == 0 && !staged) chunk = 1u << 26;  // nothing is queued at all
-	if (chunk < 64) return fail(PTX_ERR_NOMEM, "queue_bytes too small for max_ray_bounces: raise queue_bytes in ptx_scene_create");
+	const unsigned subcap = (unsigned) std::min<uint64_t>(capd / kNQ, 1u << 25);  // 64 sub-queues of it stay below 2^31 records
+	unsigned take = std::min((subcap / per_ray) & ~63u, 1u << 24);
+	if (max_depth == 0 && !staged) take = 1u << 20;  // nothing is queued at all
+	if (take < 64) return fail(PTX_ERR_NOMEM, "the work memory is too small for max_ray_bounces and the number of lights of this scene");
+	const unsigned chunk = take * kNQ;  // primary samples per launch (at most 2^30)
 	if (staged) place_staged(nqueues, capd);
 	A.out_subcap = A.in_subcap = subcap;
-	std::vector<unsigned> tails((size_t) (max_depth + 1) * kCountsPerDepth);
-	auto set_depth = [&](unsigned d, unsigned off, unsigned take) {
+	unsigned* tails = sc->tails.data();
+	auto set_depth = [&](unsigned d, unsigned first, unsigned n_take) {
 		const bool last = (d == max_depth);
 		A.depth = d;
 		A.last_depth = last;
-		A.in_offset = off;
-		A.in_take = take;
+		A.in_first = first;
+		A.in_take = n_take;
 		A.in_count = count_of(d);
 		A.out_count = count_of(d + 1);
 		if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
 		A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
 	};
-	auto rays_in = [&](const unsigned* t) {
-		uint64_t m = 0;
-		for (unsigned k = 0; k < kNQ; ++k) m += std::min(t[(size_t) k * kCountPad], subcap);  // a clipped tail raised the overflow flag
+	auto fullest = [&](const unsigned* t) {  // records in the fullest sub-queue
+		unsigned m = 0;
+		for (unsigned k = 0; k < kNQ; ++k) m = std::max(m, std::min(t[(size_t) k * kCountPad], subcap));
 		return m;
 	};
-	// rays [off0, n) of queue d in chunks; each chunk's children go to queue d+1 and are finished
-	// (recursively) before the next chunk overwrites that queue
-	auto run = [&](auto&& self, unsigned d, uint64_t off0, uint64_t n) -> PtxStatus {
-		for (uint64_t off = off0; off < n; off += chunk) {
-			unsigned cnt = (unsigned) std::min<uint64_t>(chunk, n - off);
+	// records [first0, n) of every sub-queue of queue d in slices; each slice's children go to queue
+	// d+1 and are finished (recursively) before the next slice overwrites that queue
+	auto run = [&](auto&& self, unsigned d, unsigned first0, unsigned n) -> PtxStatus {
+		for (uint64_t first = first0; first < n; first += take) {
 			const bool last = (d == max_depth);
 			if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
-			set_depth(d, (unsigned) off, cnt);
+			set_depth(d, (unsigned) first, take);
 			PtxStatus ls = launch_depth(d, ~0ull);
 			if (ls != PTX_OK) return ls;
 			if (last) continue;
-			HIP_TRY(hipMemcpyAsync(tails.data(), count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(tails, count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipStreamSynchronize(stream));
-			uint64_t m = rays_in(tails.data());
+			const unsigned m = fullest(tails);
 			if (m) {
 				PtxStatus st2 = self(self, d + 1, 0, m);
 				if (st2 != PTX_OK) return st2;
@@ -730,33 +738,33 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	};
 	for (uint64_t first = 0; first < total; first += chunk) {
 		const unsigned cnt = (unsigned) std::min<uint64_t>(chunk, total - first);
-		if (max_depth > 0) HIP_TRY(hipMemsetAsync(sc->d_counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
+		if (max_depth > 0) HIP_TRY(hipMemsetAsync(M.counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
 		if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
 		if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
 		A.first_pix = (unsigned) (first / ns);
 		A.first_s = (unsigned) (first % ns);
 		A.batch = cnt;
 		for (unsigned d = 0; d <= max_depth; ++d) {
-			set_depth(d, 0, chunk);
+			set_depth(d, 0, take);
 			PtxStatus ls = launch_depth(d, d == 0 ? (cnt + kBlock - 1) / kBlock : ~0ull);
 			if (ls != PTX_OK) return ls;
 		}
 		if (max_depth == 0) continue;
-		HIP_TRY(hipMemcpyAsync(tails.data(), count_of(1), (size_t) max_depth * kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
-		std::vector<uint64_t> held(max_depth + 1, 0);
-		for (unsigned d = 1; d <= max_depth; ++d) held[d] = rays_in(tails.data() + (size_t) (d - 1) * kCountsPerDepth);
+		unsigned held[kMaxBounces + 2] = {0};
+		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * kCountsPerDepth);
 		for (unsigned d = max_depth; d >= 1; --d) {
-			if (held[d] <= chunk) continue;
-			PtxStatus rst = run(run, d, chunk, held[d]);
+			if (held[d] <= take) continue;
+			PtxStatus rst = run(run, d, take, held[d]);
 			if (rst != PTX_OK) return rst;
 		}
 	}
 	HIP_TRY(hipGetLastError());
 	if (check_overflow || stats) {
-		Counters c;
-		if (stats) hipLaunchKernelGGL(k_stats_reduce, dim3(kMaxDepthSlots), dim3(kBlock), 0, stream, sc->d_stat, sc->d_counters);
-		HIP_TRY(hipMemcpyAsync(&c, sc->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+		Counters& c = sc->host_counters;
+		if (stats) hipLaunchKernelGGL(k_stats_reduce, dim3(kMaxDepthSlots), dim3(kBlock), 0, stream, M.stat, M.counters);
+		HIP_TRY(hipMemcpyAsync(&c, M.counters, sizeof c, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		if (stats) {
 			std::memset(stats, 0, sizeof *stats);
@@ -769,7 +777,12 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 				stats->per_depth_rays[k] = c.per_depth[k];
 				stats->per_depth_shadow[k] = c.per_depth_shadow[k];
 				stats->per_depth_hits[k] = c.per_depth_hits[k];
+				for (int j = 0; j < kTestKinds; ++j) {
+					stats->trace_tests[k][j] = c.tests[0][k][j];
+					stats->shadow_tests[k][j] = c.tests[1][k][j];
+				}
 			}
+			stats->tests_counted = count_tests ? 1 : 0;
 			if (prof)
 				for (size_t k = 0; k < sc->event_tag.size(); ++k) {
 					float ms = 0;
@@ -780,15 +793,28 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 				}
 		}
 		if (c.overflow)
-			return fail(PTX_ERR_OVERFLOW, "a ray queue overflowed (" + std::to_string(c.overflow) +
-			                                  " waves dropped rays); the image is incomplete: raise queue_bytes in ptx_scene_create");
+			return fail(PTX_ERR_OVERFLOW, "a ray queue overflowed (" + std::to_string(c.overflow) + " waves dropped rays); the image is incomplete");
 	}
 	return PTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* d_accum, void* stream_, int check_overflow,
+                                PtxStats* stats) {
+	if (!sc || !d_accum) return fail(PTX_ERR_INVALID, "scene/d_accum is NULL");
+	PtxStatus st = check_params(rp);
+	if (st != PTX_OK) return st;
+	HIP_TRY(hipSetDevice(sc->device));
+	return render_accumulate(sc, sc->work, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats);
 }
 
 PtxStatus ptx_resolve(int device, const float* d_accum, uint32_t w, uint32_t h, uint32_t spp, float* d_color, uint8_t* d_rgb8,
                       void* stream_) {
 	if (!d_accum || w == 0 || h == 0 || spp == 0) return fail(PTX_ERR_INVALID, "bad resolve arguments");
+	if ((uint64_t) w * h > 0x7fffffffull / 3) return fail(PTX_ERR_INVALID, "image too large");
 	HIP_TRY(hipSetDevice(device));
 	hipStream_t stream = static_cast<hipStream_t>(stream_);
 	// framework/renderer.cpp:86: traced_color *= 1.0f / (aa_steps_ * aa_steps_)

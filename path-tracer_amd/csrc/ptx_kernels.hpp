@@ -131,19 +131,48 @@ struct Hit {
 	int32_t slot;   // root leaf: index into root_prims
 };
 
+constexpr int kTestKinds = 5;  // slab tests, triangle tests, sphere tests, box tests, ray transforms
 struct Counters {  // cumulative over one ptx_render_accumulate (filled by k_stats_reduce)
 	unsigned long long trace_rays, shadow_rays, shaded_hits, overflow;
 	unsigned long long per_depth[kMaxDepthSlots];
 	unsigned long long per_depth_shadow[kMaxDepthSlots];
 	unsigned long long per_depth_hits[kMaxDepthSlots];
+	unsigned long long tests[2][kMaxDepthSlots][kTestKinds];  // [closest-hit kernel | shadow kernel], only with test counting on
 };
-// Work counters are kept per wave: stat[(depth_slot * kStatWaves + wave) * 4 + {trace, shadow,
-// hits}], each wave adding to its own words with plain loads and stores.  Thousands of waves
-// adding to ONE word with atomics serialise at the memory side (about 10 ns per add), which
-// costs more than the rays they count; a wave's own words are touched by nobody else during
-// a launch, and launches on one stream run in order.
-constexpr unsigned kStatWaves = 16384;
-constexpr size_t kStatBytes = (size_t) kMaxDepthSlots * kStatWaves * 4 * sizeof(unsigned long long);
+constexpr size_t kCounterBytes = 4096;
+static_assert(sizeof(Counters) <= kCounterBytes, "counter block");
+// Work counters are spread over kStatWaves slots of kStatWords words:
+// stat[(depth_slot * kStatWaves + wave % kStatWaves) * kStatWords + word], every wave adding to its
+// slot once, at its end, with no-return atomics.  Thousands of waves adding to ONE word
+// serialise at the memory side (about 10 ns per add), which costs more than the rays they
+// count; spread over thousands of words the adds proceed in parallel, and because every add
+// is an atomic it does not matter how many waves a grid has.
+//   word 0 closest-hit queries   1 shadow rays emitted   2 shaded hits
+//   3..7   tests of the closest-hit kernel (kTestKinds)   8..12 tests of the shadow kernel
+constexpr unsigned kStatWaves = 4096;
+constexpr unsigned kStatWords = 16;
+constexpr size_t kStatBytes = (size_t) kMaxDepthSlots * kStatWaves * kStatWords * sizeof(unsigned long long);
+
+// Test counting is a compile-time policy: the kernels measured for speed carry NoCount (every
+// call below vanishes), their counting twins carry TestCount and run when the caller asks for
+// the numbers.  Counted per lane that executes the test.
+struct NoCount {
+	__device__ __forceinline__ void slab(unsigned = 1) {}
+	__device__ __forceinline__ void tri() {}
+	__device__ __forceinline__ void sphere() {}
+	__device__ __forceinline__ void box() {}
+	__device__ __forceinline__ void xform() {}
+	__device__ __forceinline__ unsigned get(int) const { return 0; }
+};
+struct TestCount {
+	unsigned n[kTestKinds] = {0, 0, 0, 0, 0};
+	__device__ __forceinline__ void slab(unsigned k = 1) { n[0] += k; }
+	__device__ __forceinline__ void tri() { ++n[1]; }
+	__device__ __forceinline__ void sphere() { ++n[2]; }
+	__device__ __forceinline__ void box() { ++n[3]; }
+	__device__ __forceinline__ void xform() { ++n[4]; }
+	__device__ __forceinline__ unsigned get(int k) const { return n[k]; }
+};
 
 __device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
 
@@ -188,9 +217,9 @@ __device__ __forceinline__ float bvh_rcp(float d) {
 // far limit for node culling given the best reported distance (reported = raw - kEps)
 __device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0f * kEps + 1e-5f * fabsf(best_t)); }
 
-template <bool ANY>
+template <bool ANY, class TC>
 __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const float4* __restrict__ tris, int bvh_root, int frame, f3 o, f3 d,
-                                         int* __restrict__ stk, Hit& best, float range) {
+                                         int* __restrict__ stk, Hit& best, float range, TC& tc) {
 	// Reciprocal direction for the node tests only.  A zero (or denormal-small) component
 	// would give inf and then inf - inf = NaN inside the fused slab test, which fminf/fmaxf
 	// would read as "no constraint on the wrong side"; a huge finite reciprocal keeps the
@@ -213,6 +242,7 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 			float tn0, tn1;
 			bool h0, h1;
 			bvh_slab2(q0, q1, q2, inv, noi, limit, tn0, h0, tn1, h1);
+			tc.slab(2);
 			int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
 			if (h0 && h1) {
 				if (tn1 < tn0) {
@@ -242,6 +272,7 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 				const float4* tr = tris + (size_t) (first + k) * 3;
 				float4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
 				float t;
+				tc.tri();
 				// most tests end at the first barycentric coordinate: when they do so for the whole wave, skip the rest
 				if (!__ballot(tri_u_ok(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d))) continue;
 				if (tri_t(mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), o, d, t)) {
@@ -313,8 +344,12 @@ __device__ __forceinline__ bool may_hit_box(float4 lo, float4 hi, const RayPre& 
 // one leaf of frame 0 against a frame-0-space ray: the reference's per-shape intersect up
 // to the distance.  (1*x + 0*y) + (0*z + t*1) == x + t for finite operands, so a
 // translated-only shape gets its local origin with one addition per component.
-__device__ __forceinline__ bool root_prim_t(const DevScene& S, const DevRootPrim& P, f3 o, f3 d, const RayPre& pre, float& t) {
+template <class TC>
+__device__ __forceinline__ bool root_prim_t(const DevScene& S, const DevRootPrim& P, f3 o, f3 d, const RayPre& pre, float& t, TC& tc) {
 	const int kind = P.kind_flags & 0xff;
+	if (kind == PTX_SPHERE) tc.sphere();
+	else if (kind == PTX_BOX) tc.box();
+	else tc.tri();
 	if (P.kind_flags & kPlain) {
 		f3 lo = o + ld3(P.tinv);
 		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
@@ -323,12 +358,15 @@ __device__ __forceinline__ bool root_prim_t(const DevScene& S, const DevRootPrim
 	}
 	const Mat16 Wi = kload(reinterpret_cast<PTX_KPTR(Mat16)>(S.xforms_k + P.xform));
 	f3 lo = xform_point(Wi.m, o), ld = xform_dir(Wi.m, d);
+	tc.xform();
 	if (kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
 	if (kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
 	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
 }
 
-__device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, int f, f3 o, f3 d, f3& lo, f3& ld) {
+template <class TC>
+__device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, int f, f3 o, f3 d, f3& lo, f3& ld, TC& tc) {
+	tc.xform();
 	if (F.plain) {
 		lo = o + ld3(F.tinv);
 		ld = d;
@@ -341,10 +379,14 @@ __device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, 
 
 // The same test with the leaf chosen per lane (ordinary loads instead of scalar ones): the
 // leaves of a large frame 0 are reached through a BVH, and lanes arrive at different ones.
-__device__ __forceinline__ bool root_prim_t_lane(const DevScene& S, int slot, f3 o, f3 d, const RayPre& pre, float& t, int& id) {
+template <class TC>
+__device__ __forceinline__ bool root_prim_t_lane(const DevScene& S, int slot, f3 o, f3 d, const RayPre& pre, float& t, int& id, TC& tc) {
 	const DevRootPrim& P = S.root_prims[slot];
 	const int kf = P.kind_flags, kind = kf & 0xff;
 	id = P.id;
+	if (kind == PTX_SPHERE) tc.sphere();
+	else if (kind == PTX_BOX) tc.box();
+	else tc.tri();
 	if (kf & kPlain) {
 		f3 lo = o + ld3(P.tinv);
 		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
@@ -353,6 +395,7 @@ __device__ __forceinline__ bool root_prim_t_lane(const DevScene& S, int slot, f3
 	}
 	const float* Wi = S.xforms[slot].winv;
 	f3 lo = xform_point(Wi, o), ld = xform_dir(Wi, d);
+	tc.xform();
 	if (kind == PTX_SPHERE) return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
 	if (kind == PTX_BOX) return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
 	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
@@ -362,8 +405,8 @@ __device__ __forceinline__ bool root_prim_t_lane(const DevScene& S, int slot, f3
 // more than a handful; the reference walks its root's children one by one,
 // composite.cpp:75-103).  Same conservative node test, same two nested loops; a leaf holds up
 // to four shapes of any kind, each tested with the reference's arithmetic.
-template <bool ANY>
-__device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const RayPre& pre, int* __restrict__ stk, Hit& best, float range) {
+template <bool ANY, class TC>
+__device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const RayPre& pre, int* __restrict__ stk, Hit& best, float range, TC& tc) {
 	const float4* __restrict__ nodes = S.nodes + S.root_node_base;
 	const f3 inv = pre.finv, noi = pre.fnoi;
 	constexpr int kDone = (int) 0x80000000;
@@ -377,6 +420,7 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 			float tn0, tn1;
 			bool h0, h1;
 			bvh_slab2(q0, q1, q2, inv, noi, limit, tn0, h0, tn1, h1);
+			tc.slab(2);
 			int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
 			if (h0 && h1) {
 				if (tn1 < tn0) {
@@ -405,7 +449,7 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 			for (int k = 0; k < cnt; ++k) {
 				float t;
 				int id;
-				if (root_prim_t_lane(S, first + k, o, d, pre, t, id)) {
+				if (root_prim_t_lane(S, first + k, o, d, pre, t, id, tc)) {
 					if (ANY) {
 						if (t <= range) return true;
 					} else if (t < best.t || (t == best.t && id < best.id)) {
@@ -437,23 +481,25 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 //   closest_frames  the mesh frames; with `known` a frame below 32 is walked iff its bit is set
 // (RB: the kernel variant for scenes whose frame-0 leaves sit under a BVH; the variant without
 // it still gives the same answers on such a scene, leaf by leaf)
-template <bool RB>
-__device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, const RayPre& pre, int* __restrict__ stk, Hit& best) {
+template <bool RB, class TC>
+__device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, const RayPre& pre, int* __restrict__ stk, Hit& best, TC& tc) {
 	best.t = kInf;
 	best.id = -1;
 	best.frame = 0;
 	best.slot = 0;
 	float unused;
+	tc.slab();
 	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return false;
 	if (RB && S.root_bvh) {
-		root_walk<false>(S, o, d, pre, stk, best, 0.0f);
+		root_walk<false>(S, o, d, pre, stk, best, 0.0f, tc);
 		return true;
 	}
 	for (int i = 0; i < S.n_root_prims; ++i) {
+		tc.slab();
 		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
 		float t;
-		const bool hit = root_prim_t(S, P, o, d, pre, t);
+		const bool hit = root_prim_t(S, P, o, d, pre, t, tc);
 		const bool better = hit && (t < best.t || (t == best.t && P.id < best.id));
 		best.t = better ? t : best.t;
 		best.id = better ? P.id : best.id;
@@ -461,64 +507,78 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	}
 	return true;
 }
-__device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, const RayPre& pre) {
+template <class TC>
+__device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, const RayPre& pre, TC& tc) {
 	unsigned mask = S.n_frames > 32 ? 1u : 0u;
 	float unused;
 	const int nf = S.n_frames < 32 ? S.n_frames : 32;
 	for (int f = 1; f < nf; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
+		tc.slab();
 		if (box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) mask |= 1u << f;
 	}
 	return mask;
 }
-template <bool KNOWN>
-__device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, const RayPre& pre, unsigned known, int* __restrict__ stk, Hit& best) {
+template <bool KNOWN, class TC>
+__device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, const RayPre& pre, unsigned known, int* __restrict__ stk, Hit& best, TC& tc) {
 	float unused;
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
 		if (KNOWN && f < 32) {
 			if (!(known >> f & 1u)) continue;
-		} else if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
+		} else {
+			tc.slab();
+			if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
+		}
 		f3 lo, ld;
-		frame_ray(S, F, f, o, d, lo, ld);
-		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f);
+		frame_ray(S, F, f, o, d, lo, ld, tc);
+		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc);
 	}
 }
 template <bool RB = false>
 __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
 	const RayPre pre = ray_pre(S, o, d);
-	if (!closest_root<RB>(S, o, d, pre, stk, best)) return;
-	closest_frames<false>(S, o, d, pre, 0u, stk, best);
+	NoCount tc;
+	if (!closest_root<RB>(S, o, d, pre, stk, best, tc)) return;
+	closest_frames<false>(S, o, d, pre, 0u, stk, best, tc);
 }
 
 // find_light_block(...).does_intersect, framework/renderer.cpp:168-175: the closest hit
 // lies within `range`  <=>  some leaf is hit at distance <= range.
-template <bool RB = false>
-__device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
+template <bool RB, class TC>
+__device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk, TC& tc) {
 	float t;
 	RayPre pre = ray_pre(S, o, d);
+	tc.slab();
 	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, t)) return false;
 	Hit dummy;
 	if (RB && S.root_bvh) {
-		if (root_walk<true>(S, o, d, pre, stk, dummy, range)) return true;
+		if (root_walk<true>(S, o, d, pre, stk, dummy, range, tc)) return true;
 	} else {
 		for (int i = 0; i < S.n_root_prims; ++i) {
+			tc.slab();
 			if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
 			const DevRootPrim P = kload(S.root_prims_k + i);
-			if (root_prim_t(S, P, o, d, pre, t) && t <= range) return true;
+			if (root_prim_t(S, P, o, d, pre, t, tc) && t <= range) return true;
 		}
 	}
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
+		tc.slab();
 		if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, t)) continue;
 		f3 lo, ld;
-		frame_ray(S, F, f, o, d, lo, ld);
-		if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range)) return true;
+		frame_ray(S, F, f, o, d, lo, ld, tc);
+		if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range, tc)) return true;
 	}
 	return false;
+}
+template <bool RB = false>
+__device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float range, int* __restrict__ stk) {
+	NoCount tc;
+	return trace_any<RB>(S, o, d, range, stk, tc);
 }
 
 struct Surface {  // the HitPoint fields shading reads, framework/hitPoint.hpp:8-16
@@ -737,7 +797,10 @@ __device__ __forceinline__ unsigned long long lanes_below(unsigned lane) { retur
 
 // Adds `v` of the lanes with `has` into accum[pix*3..]: the wave is cut into runs of
 // consecutive lanes with equal pixel (rays stay in pixel order through compaction), each
-// run is summed with shuffles and its first lane issues the three atomics.
+// run is summed with shuffles, and the run's first three lanes add its r, g and b to three
+// consecutive words with ONE atomic instruction (float atomics execute at the memory side,
+// one request per 64-byte line an instruction touches: three instructions of one lane each
+// were three requests per run).  A run of one or two lanes adds the rest from its first lane.
 __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned pix, f3 v, bool has) {
 	const unsigned long long has_mask = __ballot(has);
 	if (has_mask == 0) return;
@@ -758,16 +821,17 @@ __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned p
 			v.z += oz;
 		}
 	}
-	if (head) {
-		const unsigned run = above ? (unsigned) __builtin_ctzll(above) + 1 : 64 - lane;  // lanes in my run
-		const unsigned long long mine = has_mask >> lane;
-		if (run >= 64 ? mine != 0 : (mine & ((1ull << run) - 1)) != 0) {
-			float* p = accum + (size_t) pix * 3;
-			atomicAdd(p, v.x);
-			atomicAdd(p + 1, v.y);
-			atomicAdd(p + 2, v.z);
-		}
-	}
+	const unsigned run = above ? (unsigned) __builtin_ctzll(above) + 1 : 64 - lane;  // lanes from here to the end of my run
+	const unsigned long long mine = has_mask >> lane;
+	const bool live = head && (run >= 64 ? mine != 0 : (mine & ((1ull << run) - 1)) != 0);  // first lane of a run that has something to add
+	const unsigned long long live_heads = __ballot(live);
+	const float y1 = __shfl_up(v.y, 1), z2 = __shfl_up(v.z, 2);
+	const bool second = !head && lane >= 1 && (live_heads >> (lane - 1) & 1);
+	const bool third = !head && lane >= 2 && !(heads >> (lane - 1) & 1) && (live_heads >> (lane - 2) & 1);
+	float* p = accum + (size_t) pix * 3;
+	if (live || second || third) atomicAdd(p + (live ? 0 : second ? 1 : 2), live ? v.x : second ? y1 : z2);
+	if (live && run < 2) atomicAdd(p + 1, v.y);
+	if (live && run < 3) atomicAdd(p + 2, v.z);
 }
 
 // u / n and u % n for u < 2^31 with inv = 1.0 / n in double: the product is below the true
@@ -804,6 +868,19 @@ __device__ __forceinline__ void make_primary(const DevCamera& cam, unsigned pixe
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+// Queues.  A queue (rays of one depth, shadow rays, hit records) is cut into kNQ sub-queues
+// with separate tail counters.  The work of a launch is dealt to the waves in UNITS of 64
+// records: unit u is records [64 k, 64 k + 64) of sub-queue q, with q = u mod kNQ and
+// k = u / kNQ (depth 0, where the rays are generated: samples [64 u, 64 u + 64) of the batch).
+// Everything a unit produces - hit records, child rays, shadow rays - goes to sub-queue q of
+// the respective output queue.  So:
+//   * a record's place follows from (q, k, lane) alone: no prefix sums over the sub-queues, no
+//     search, and a hit record names its ray by its slot in the queue;
+//   * sub-queue q of an output holds at most (records taken from sub-queue q of the input) x
+//     (records one input can produce), whatever the waves do in between (parking rays, walking
+//     them later): the host sizes `in_take` from that and nothing can overflow;
+//   * the 64 sub-queues stay equally full (consecutive 64-sample steps of the image go to
+//     consecutive sub-queues), which is what keeps the units of a launch equally long.
 struct BounceArgs {
 	DevScene S;
 	DevCamera cam;
@@ -812,89 +889,79 @@ struct BounceArgs {
 	unsigned* out_count;       // kNQ tail counters of `out`
 	unsigned out_subcap;       // slots per sub-queue of `out`
 	unsigned in_subcap;
-	unsigned in_offset;        // first ray (in the concatenation of the sub-queues) this launch takes
-	unsigned in_take;          // rays this launch takes from in_offset on; 0 = all of them
+	unsigned in_first;         // depth > 0: the launch takes records [in_first, in_first + in_take) of every sub-queue of `in`
+	unsigned in_take;          // (0 = all from in_first on)
 	unsigned first_pix, first_s;  // depth 0: the batch starts at sample first_s (< ns) of this render's range in pixel first_pix
 	double inv_ns;             // 1.0 / ns
-	unsigned batch;            // depth 0: samples in the batch; depth > 0 with in_count == NULL: rays to take
+	unsigned batch;            // depth 0: samples in the batch
 	unsigned ns, s0;           // samples per pixel in this render's range, first sample
 	unsigned depth;
 	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
 	float* accum;
 	Counters* counters;        // overflow flag only
-	unsigned long long* stat;  // per-wave work counters
+	unsigned long long* stat;  // work counters, spread over kStatWaves slots
 	// staged pipeline only
 	RayQueue shadow;           // a = (o.xyz, bits(pixel))  b = (contribution rgb, bits(light)); plane c unused (32 B per shadow ray)
 	unsigned* shadow_count;    // kNQ tail counters of `shadow`
 	unsigned shadow_subcap;
-	float4* hits;              // hit list of the launch, sub-queued like the ray queues: (t, bits(prim id), bits(where), bits(ray index))
+	float4* hits;              // hit list of the launch, sub-queued like the ray queues: (t, bits(prim id), bits(where), bits(ray))
+	                           // ray = the sample's index in the batch (depth 0) or the ray's slot in `in`
 	unsigned* hit_count;       // kNQ tail counters of `hits`
 	unsigned hit_subcap;
 };
 
-// Records held by a sub-queued queue: fills pfx (in LDS) with the first record index of every
-// sub-queue in their concatenation and returns how many of the records from `offset` on the
-// launch takes (`take` = 0: all of them).  All threads of the workgroup must call it.
-__device__ __forceinline__ unsigned queue_input(const unsigned* count, unsigned subcap, unsigned* pfx, unsigned offset, unsigned take) {
-	const unsigned lane = lane_id();
+// Records the launch takes of every sub-queue -> cnt[0..kNQ) in LDS (cnt[kNQ] = their maximum);
+// returns the number of units.  All threads of the workgroup must call it.
+__device__ __forceinline__ unsigned sub_counts(const unsigned* count, unsigned subcap, unsigned first, unsigned take, unsigned* cnt) {
 	if (threadIdx.x < 64) {
 		unsigned c = min(count[threadIdx.x * kCountPad], subcap);
-		for (int off = 1; off < 64; off <<= 1) {
-			unsigned t = __shfl_up(c, off);
-			if (lane >= (unsigned) off) c += t;
-		}
-		pfx[lane + 1] = c;
-		if (lane == 0) pfx[0] = 0;
+		c = c > first ? c - first : 0;
+		if (take) c = min(c, take);
+		cnt[threadIdx.x] = c;
+		unsigned m = c;
+		for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned) __shfl_xor((int) m, off));
+		if (threadIdx.x == 0) cnt[kNQ] = m;
 	}
 	__syncthreads();
-	const unsigned total_in = pfx[kNQ];
-	const unsigned avail = total_in > offset ? total_in - offset : 0;
-	return take ? min(take, avail) : avail;
+	return ((cnt[kNQ] + 63) >> 6) * kNQ;
 }
-// number of input rays of a launch: the primary batch, or what the launch takes of queue `in`
+// units of a launch: the primary batch, or what the launch takes of queue `in`
 template <bool PRIMARY>
-__device__ __forceinline__ unsigned launch_input(const BounceArgs& A, unsigned* pfx) {
-	if (PRIMARY) return A.batch;
-	return queue_input(A.in_count, A.in_subcap, pfx, A.in_offset, A.in_take);
+__device__ __forceinline__ unsigned launch_units(const BounceArgs& A, unsigned* cnt) {
+	if (PRIMARY) return (A.batch + 63) >> 6;
+	return sub_counts(A.in_count, A.in_subcap, A.in_first, A.in_take, cnt);
 }
-
-// ray index of the launch -> record index in a sub-queued queue (binary search over pfx)
-__device__ __forceinline__ size_t queue_slot(const unsigned* pfx, unsigned subcap, unsigned g) {
-	unsigned lo_q = 0, hi_q = kNQ;
-#pragma unroll
-	for (int it = 0; it < 6; ++it) {
-		unsigned mid = (lo_q + hi_q) >> 1;
-		bool ge = pfx[mid] <= g;
-		lo_q = ge ? mid : lo_q;
-		hi_q = ge ? hi_q : mid;
+// lane's record of unit u: `ref` = sample index in the batch (depth 0) or slot in `in`; false = no record
+template <bool PRIMARY>
+__device__ __forceinline__ bool unit_record(const BounceArgs& A, const unsigned* cnt, unsigned u, unsigned lane, unsigned& ref) {
+	if (PRIMARY) {
+		ref = u * 64 + lane;
+		return ref < A.batch;
 	}
-	return (size_t) lo_q * subcap + (g - pfx[lo_q]);
+	const unsigned q = u & (kNQ - 1), r = (u >> 6) * 64 + lane;
+	ref = q * A.in_subcap + A.in_first + r;
+	return r < cnt[q];
 }
 
-// the i-th input ray of a launch: generated (depth 0, framework/renderer.cpp:76-82) or read from `in`
+// the input ray behind `ref`: generated (depth 0, framework/renderer.cpp:76-82) or read from `in`
 template <bool PRIMARY>
-__device__ __forceinline__ void input_ray(const BounceArgs& A, const unsigned* pfx, unsigned i, f3& o, f3& d, f3& w, unsigned& pix) {
+__device__ __forceinline__ void input_ray(const BounceArgs& A, unsigned ref, f3& o, f3& d, f3& w, unsigned& pix) {
 	if (PRIMARY) {
 		unsigned dp, s;
-		udivmod(A.first_s + i, A.ns, A.inv_ns, dp, s);
+		udivmod(A.first_s + ref, A.ns, A.inv_ns, dp, s);
 		pix = A.first_pix + dp;
 		s += A.s0;
 		make_primary(A.cam, pix, s, o, d);
 		w = mk(1, 1, 1);
 	} else {
-		const size_t j = queue_slot(pfx, A.in_subcap, A.in_offset + i);
-		const float4 a = A.in.a[j], b = A.in.b[j];
-		const float2 c = A.in.c[j];
+		const float4 a = A.in.a[ref], b = A.in.b[ref];
+		const float2 c = A.in.c[ref];
 		o = mk(a.x, a.y, a.z);
 		d = mk(a.w, b.x, b.y);
 		w = mk(b.z, b.w, c.x);
 		pix = __float_as_uint(c.y);
 	}
 }
-
-// Sub-queue that takes the records a wave emits for the step starting at ray `base` of a
-// launch: the steps go round the sub-queues.
-__device__ __forceinline__ unsigned sub_queue_of(unsigned long long base) { return (unsigned) (base >> 6) & (kNQ - 1); }
 
 // wave64 ballot compaction of up to two records per lane into sub-queue q of a queue: the
 // records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.  The
@@ -905,14 +972,17 @@ struct Reserved {
 	unsigned q;
 	unsigned long long m1, m2;
 };
-__device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned long long base, bool live1, bool live2) {
+__device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned q, bool live1, bool live2) {
 	Reserved R;
 	R.m1 = __ballot(live1);
 	R.m2 = __ballot(live2);
 	R.slot0 = 0;
 	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
-	R.q = sub_queue_of(base);
-	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + R.q * kCountPad, total);
+	R.q = q;
+	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + q * kCountPad, total);
+#ifdef EXP_DOUBLE_RESERVE
+	if (total && lane_id() == 0) R.slot0 += atomicAdd(tails + q * kCountPad + 16, 0u) & 0u;
+#endif
 	return R;
 }
 template <bool WITH_C = true>
@@ -939,11 +1009,11 @@ __device__ __forceinline__ void emit_write(const RayQueue& Q, unsigned subcap, c
 		Q.b[qbase + my] = r2[1];
 		if (WITH_C) Q.c[qbase + my] = make_float2(r2[2].x, r2[2].y);
 	}
-	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);
+	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);  // (the host's sizing rules this out; kept as a tripwire)
 }
-__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned long long base, bool live1,
+__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned q, bool live1,
                                           const float4 r1[3], bool live2, const float4 r2[3], Counters* counters) {
-	const Reserved R = emit_reserve(tails, base, live1, live2);
+	const Reserved R = emit_reserve(tails, q, live1, live2);
 	emit_write(Q, subcap, R, live1, r1, live2, r2, counters);
 }
 
@@ -953,46 +1023,42 @@ __device__ __forceinline__ void pack_child(const Child& c, unsigned pix, float4 
 	r[2] = make_float4(c.w.z, __uint_as_float(pix), 0.f, 0.f);
 }
 
-__device__ __forceinline__ void wave_stats(const BounceArgs& A, unsigned wave, unsigned trace, unsigned shadow, unsigned hits) {
-	for (int off = 32; off > 0; off >>= 1) {
-		trace += __shfl_down(trace, off);
-		shadow += __shfl_down(shadow, off);
-		hits += __shfl_down(hits, off);
-	}
-	if (lane_id() == 0 && (trace | shadow | hits)) {
-		unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
-		unsigned long long* st = A.stat + ((size_t) slot * kStatWaves + (wave % kStatWaves)) * 4;
-		if (wave < kStatWaves) {
-			st[0] += trace;
-			st[1] += shadow;
-			st[2] += hits;
-		} else {  // more waves than slots (cannot happen with the grids this file launches)
-			atomicAdd(st, (unsigned long long) trace);
-			atomicAdd(st + 1, (unsigned long long) shadow);
-			atomicAdd(st + 2, (unsigned long long) hits);
-		}
-	}
+// a wave's share of the work counters, added once at its end (layout: kStatWords)
+__device__ __forceinline__ unsigned long long* stat_slot(const BounceArgs& A, unsigned wave) {
+	const unsigned slot = A.depth < kMaxDepthSlots ? A.depth : kMaxDepthSlots - 1;
+	return A.stat + ((size_t) slot * kStatWaves + (wave % kStatWaves)) * kStatWords;
 }
+__device__ __forceinline__ void stat_add(unsigned long long* st, int word, unsigned per_lane) {
+	unsigned long long v = per_lane;
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+	if (lane_id() == 0 && v) atomicAdd(st + word, v);
+}
+template <class TC>
+__device__ __forceinline__ void stat_add_tests(unsigned long long* st, int first_word, const TC& tc) {
+	for (int k = 0; k < kTestKinds; ++k) stat_add(st, first_word + k, tc.get(k));
+}
+template <>
+__device__ __forceinline__ void stat_add_tests<NoCount>(unsigned long long*, int, const NoCount&) {}
 
 // ---- fused pipeline: one kernel per depth -----------------------------------------------
 template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned pfx[kNQ + 1];
+	__shared__ unsigned cnt[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, pfx);
+	const unsigned units = launch_units<PRIMARY>(A, cnt);
 	const unsigned waves_per_block = kBlock / 64;
 	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * waves_per_block;
 	unsigned cnt_trace = 0, cnt_shadow = 0, cnt_hits = 0;
 
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
-		bool active = i < n;
+	for (unsigned u = wave; u < units; u += n_waves) {
+		unsigned ref;
+		const bool active = unit_record<PRIMARY>(A, cnt, u, lane, ref);
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
-		if (active) input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+		if (active) input_ray<PRIMARY>(A, ref, o, d, w, pix);
 		Hit h;
 		h.id = -1;
 		if (active) {
@@ -1012,9 +1078,12 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 		float4 r1[3], r2[3];
 		pack_child(refl, pix, r1);
 		pack_child(refr, pix, r2);
-		emit_pair(A.out, A.out_count, A.out_subcap, base, refl.live, r1, refr.live, r2, A.counters);
+		emit_pair(A.out, A.out_count, A.out_subcap, u & (kNQ - 1), refl.live, r1, refr.live, r2, A.counters);
 	}
-	wave_stats(A, wave, cnt_trace, cnt_shadow, cnt_hits);
+	unsigned long long* st = stat_slot(A, wave);
+	stat_add(st, 0, cnt_trace);
+	stat_add(st, 1, cnt_shadow);
+	stat_add(st, 2, cnt_hits);
 }
 
 // ---- staged pipeline: closest hit / shading / shadow rays as three lean kernels ---------
@@ -1025,30 +1094,31 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 // Only some of a step's 64 rays get as far as a mesh; the others are settled by the leaves of
 // frame 0 or miss every mesh's bounds.  Walking a BVH with the few that remain leaves most
 // lanes idle (measured: 13 of 64 on the incoherent depths), so unless most of the step goes
-// on (kWalkNow lanes) the wave parks those rays - ray index and the best hit so far - in a
-// small ring in LDS and walks once 64 of them have gathered, with every lane busy at the start.
+// on (kWalkNow lanes) the wave parks those rays - their slot in the queue and the best hit so
+// far - in a small ring in LDS and walks once 64 of them have gathered, with every lane busy
+// at the start.
 constexpr unsigned kRing = 128;    // parked rays per wave
 constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
-template <bool PRIMARY, bool RB>
+template <bool PRIMARY, bool RB, class TC>
 __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned pfx[kNQ + 1];
+	__shared__ unsigned cnt[kNQ + 1];
 	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
 	int* stk = lds_stack + threadIdx.x;
 	volatile float4* ring = ring_mem + (threadIdx.x >> 6) * kRing;
 	const unsigned lane = lane_id();
-	const unsigned n = launch_input<PRIMARY>(A, pfx);
+	const unsigned units = launch_units<PRIMARY>(A, cnt);
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	unsigned cnt_trace = 0;
-	unsigned parked = 0, emits = wave;  // the same in every lane
-	// the hit records of the lanes with `hit`, compacted, into one sub-list (keeping them in
+	TC tc;
+	unsigned parked = 0, parked_q = 0;  // the same in every lane; the parked rays all come from sub-queue parked_q
+	// the hit records of the lanes with `hit`, compacted, into sub-list q (keeping them in
 	// registers until the atomic's answer has arrived, a step later, was measured: no gain)
-	auto emit = [&](bool hit, const Hit& h, unsigned i) {
+	auto emit = [&](unsigned q, bool hit, const Hit& h, unsigned ref) {
 		const unsigned long long m = __ballot(hit);
 		if (!m) return;
 		const unsigned total = __builtin_popcountll(m);
-		const unsigned q = sub_queue_of((unsigned long long) emits++ << 6);
 		unsigned slot0 = 0;
 		if (lane == 0) slot0 = atomicAdd(A.hit_count + q * kCountPad, total);
 		slot0 = __shfl(slot0, 0);
@@ -1056,8 +1126,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
 		const int where = h.frame == 0 ? h.slot : -h.frame;
 		if (hit && my < A.hit_subcap)
-			A.hits[(size_t) q * A.hit_subcap + my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(i));
-		if (lane == 0 && slot0 + total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);
+			A.hits[(size_t) q * A.hit_subcap + my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(ref));
+		if (lane == 0 && slot0 + total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);  // (cannot happen: a ray leaves at most one hit)
 	};
 	// the mesh walks of the `count` most recently parked rays
 	auto walk_parked = [&](unsigned count) {
@@ -1066,24 +1136,29 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		h.frame = 0;
 		h.slot = 0;
 		h.t = kInf;
-		unsigned i = 0;
+		unsigned ref = 0;
 		if (lane < count) {
 			const volatile float4* rq = ring + (parked - count + lane);
 			h.t = rq->x;
 			h.id = __float_as_int(rq->y);
 			h.slot = __float_as_int(rq->z);
-			i = __float_as_uint(rq->w);
+			ref = __float_as_uint(rq->w);
 			f3 o, d, w;
 			unsigned pix;
-			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+			input_ray<PRIMARY>(A, ref, o, d, w, pix);
 			const RayPre pre = ray_pre(A.S, o, d);
-			closest_frames<false>(A.S, o, d, pre, 0u, stk, h);
+			closest_frames<false>(A.S, o, d, pre, 0u, stk, h, tc);
 		}
 		parked -= count;
-		emit(h.id >= 0, h, i);
+		emit(parked_q, h.id >= 0, h, ref);
 	};
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
+	for (unsigned u = wave; u < units; u += n_waves) {
+		const unsigned q = u & (kNQ - 1);
+		// (a grid of a multiple of 16 workgroups keeps a wave on one sub-queue; otherwise the
+		// rays parked so far are walked before the wave moves to another)
+		if (parked && q != parked_q) walk_parked(parked);
+		unsigned ref;
+		const bool active = unit_record<PRIMARY>(A, cnt, u, lane, ref);
 		Hit h;
 		h.id = -1;
 		h.frame = 0;
@@ -1092,64 +1167,65 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		f3 o = {0, 0, 0}, d = {0, 0, 1}, w;
 		unsigned pix, frames = 0;
 		RayPre pre = ray_pre(A.S, o, d);
-		if (i < n) {
-			input_ray<PRIMARY>(A, pfx, i, o, d, w, pix);
+		if (active) {
+			input_ray<PRIMARY>(A, ref, o, d, w, pix);
 			pre = ray_pre(A.S, o, d);
-			if (closest_root<RB>(A.S, o, d, pre, stk, h)) frames = frame_mask(A.S, o, d, pre);
+			if (closest_root<RB>(A.S, o, d, pre, stk, h, tc)) frames = frame_mask(A.S, o, d, pre, tc);
 			++cnt_trace;
 		}
 		bool park = frames != 0;
 		const unsigned long long m = __ballot(park);
-		const unsigned cnt = __builtin_popcountll(m);
+		const unsigned np = __builtin_popcountll(m);
 		// most of the wave goes on to a mesh (or these are primary rays, neighbours in the image):
 		// walk here, the rays are in registers
-		const bool walk_now = PRIMARY || cnt >= kWalkNow;
+		const bool walk_now = PRIMARY || np >= kWalkNow;
 		if (walk_now) {
-			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h);
+			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h, tc);
 			park = false;
 		}
-		emit(h.id >= 0 && !park, h, i);
-		if (cnt && !walk_now) {
-			if (parked + cnt > kRing) walk_parked(parked < 64 ? parked : 64);
+		emit(q, h.id >= 0 && !park, h, ref);
+		if (np && !walk_now) {
+			if (parked + np > kRing) walk_parked(parked < 64 ? parked : 64);
 			if (park) {
 				volatile float4* rq = ring + (parked + __builtin_popcountll(m & lanes_below(lane)));
 				rq->x = h.t;
 				rq->y = __int_as_float(h.id);
 				rq->z = __int_as_float(h.slot);
-				rq->w = __uint_as_float(i);
+				rq->w = __uint_as_float(ref);
 			}
-			parked += cnt;
+			parked += np;
+			parked_q = q;
 			if (parked >= 64) walk_parked(64);
 		}
 	}
 	if (parked) walk_parked(parked);
-	wave_stats(A, wave, cnt_trace, 0, 0);
+	unsigned long long* st = stat_slot(A, wave);
+	stat_add(st, 0, cnt_trace);
+	stat_add_tests(st, 3, tc);
 }
 
 template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) {
-	__shared__ unsigned pfx_hit[kNQ + 1];
-	__shared__ unsigned pfx[kNQ + 1];
-	const unsigned n = queue_input(A.hit_count, A.hit_subcap, pfx_hit, 0, 0);
-	if (!PRIMARY) (void) launch_input<false>(A, pfx);
+	__shared__ unsigned cnt[kNQ + 1];
+	const unsigned units = sub_counts(A.hit_count, A.hit_subcap, 0, 0, cnt);
+	const unsigned lane = lane_id();
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
 	unsigned cnt_shadow = 0, cnt_hits = 0;
-	// the hit record of a step is fetched one step ahead, so that its trip from memory runs
-	// beside the previous step's work instead of in front of this step's
-	const unsigned long long stride = (unsigned long long) n_waves * 64;
-	auto fetch_hit = [&](unsigned long long b) {
-		const unsigned j = (unsigned) b + lane_id();
-		return j < n ? A.hits[queue_slot(pfx_hit, A.hit_subcap, j)] : make_float4(0.f, 0.f, 0.f, 0.f);
+	// the hit record of a unit is fetched one unit ahead, so that its trip from memory runs
+	// beside the previous unit's work instead of in front of this unit's
+	auto fetch_hit = [&](unsigned u) {
+		const unsigned q = u & (kNQ - 1), r = (u >> 6) * 64 + lane;
+		return r < cnt[q] ? A.hits[(size_t) q * A.hit_subcap + r] : make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
 	};
-	unsigned long long base = (unsigned long long) wave * 64;
-	float4 hr_next = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (base < n) hr_next = fetch_hit(base);
-	for (; base < n; base += stride) {
-		const unsigned i = (unsigned) base + lane_id();
-		const bool hit = i < n;
+	unsigned u = wave;
+	float4 hr_next = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
+	if (u < units) hr_next = fetch_hit(u);
+	for (; u < units; u += n_waves) {
+		const unsigned q = u & (kNQ - 1);
 		const float4 hr = hr_next;
-		if (base + stride < n) hr_next = fetch_hit(base + stride);
+		const bool hit = __float_as_int(hr.y) >= 0;
+		if (u + n_waves < units) hr_next = fetch_hit(u + n_waves);
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
 		Surface sf;
@@ -1166,7 +1242,7 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 			const int where = __float_as_int(hr.z);
 			h.frame = where < 0 ? -where : 0;
 			h.slot = where < 0 ? 0 : where;
-			input_ray<PRIMARY>(A, pfx, __float_as_uint(hr.w), o, d, w, pix);
+			input_ray<PRIMARY>(A, __float_as_uint(hr.w), o, d, w, pix);
 			sf = surface_of(A.S, o, d, h);
 			Material M = load_material(A.S, h.id);
 			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
@@ -1181,7 +1257,7 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 		}
 		// the slots of the child rays are asked for first and used last: the light terms, the
 		// shadow records and the accumulation all fit inside that atomic's round trip
-		const Reserved rc = emit_reserve(A.out_count, base, refl.live, refr.live);
+		const Reserved rc = emit_reserve(A.out_count, q, refl.live, refr.live);
 		bool accumulated = false;
 		// one shadow ray per light whose term can add something; its record carries the finished
 		// contribution weight * ((diffuse + specular) * opacity * k1)
@@ -1200,7 +1276,7 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 				r[2] = r[1];
 			}
 			if (want) ++cnt_shadow;
-			const Reserved rs = emit_reserve(A.shadow_count, base, want, false);
+			const Reserved rs = emit_reserve(A.shadow_count, q, want, false);
 			if (!accumulated) accumulate(A.accum, pix, contrib, hit);
 			accumulated = true;
 			emit_write<false>(A.shadow, A.shadow_subcap, rs, want, r, false, r, A.counters);
@@ -1211,28 +1287,31 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 		pack_child(refr, pix, r2);
 		emit_write(A.out, A.out_subcap, rc, refl.live, r1, refr.live, r2, A.counters);
 	}
-	wave_stats(A, wave, 0, cnt_shadow, cnt_hits);
+	unsigned long long* st = stat_slot(A, wave);
+	stat_add(st, 1, cnt_shadow);
+	stat_add(st, 2, cnt_hits);
 }
 
 // find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
 // unblocked ray adds its contribution to its pixel
-template <bool RB>
+template <bool RB, class TC>
 __global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned pfx[kNQ + 1];
+	__shared__ unsigned cnt[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned n = queue_input(A.shadow_count, A.shadow_subcap, pfx, 0, 0);
+	const unsigned units = sub_counts(A.shadow_count, A.shadow_subcap, 0, 0, cnt);
 	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	const unsigned n_waves = gridDim.x * (kBlock / 64);
-	for (unsigned long long base = (unsigned long long) wave * 64; base < n; base += (unsigned long long) n_waves * 64) {
-		unsigned i = (unsigned) base + lane;
-		bool active = i < n;
+	TC tc;
+	for (unsigned u = wave; u < units; u += n_waves) {
+		const unsigned q = u & (kNQ - 1), r = (u >> 6) * 64 + lane;
+		const bool active = r < cnt[q];
 		unsigned pix = 0;
 		f3 c = {0, 0, 0};
 		bool lit = false;
 		if (active) {
-			const size_t j = queue_slot(pfx, A.shadow_subcap, i);
+			const size_t j = (size_t) q * A.shadow_subcap + r;
 			const float4 a = A.shadow.a[j], b = A.shadow.b[j];
 			pix = __float_as_uint(a.w);
 			c = mk(b.x, b.y, b.z);
@@ -1242,42 +1321,43 @@ __global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 			f3 ldir = mk(lp.x, lp.y, lp.z) - pos;
 			const float dist = length(ldir);
 			ldir = normalize(ldir);
-			lit = !trace_any<RB>(A.S, pos, ldir, dist, stk);
+			lit = !trace_any<RB>(A.S, pos, ldir, dist, stk, tc);
 		}
 		accumulate(A.accum, pix, c, lit);
 	}
+	stat_add_tests(stat_slot(A, wave), 3 + kTestKinds, tc);
 }
 
-// sums the per-wave statistic words into the compact block the host reads
+// sums the statistic slots of one depth into the compact block the host reads
 __global__ __launch_bounds__(kBlock) void k_stats_reduce(const unsigned long long* __restrict__ stat, Counters* __restrict__ out) {
-	__shared__ unsigned long long red[kBlock * 3];
+	__shared__ unsigned long long red[kBlock];
 	const unsigned depth = blockIdx.x;
-	unsigned long long a = 0, b = 0, c = 0;
-	for (unsigned w = threadIdx.x; w < kStatWaves; w += kBlock) {
-		const unsigned long long* st = stat + ((size_t) depth * kStatWaves + w) * 4;
-		a += st[0];
-		b += st[1];
-		c += st[2];
-	}
-	red[threadIdx.x] = a;
-	red[kBlock + threadIdx.x] = b;
-	red[2 * kBlock + threadIdx.x] = c;
-	__syncthreads();
-	for (unsigned s = kBlock / 2; s > 0; s >>= 1) {
-		if (threadIdx.x < s) {
-			red[threadIdx.x] += red[threadIdx.x + s];
-			red[kBlock + threadIdx.x] += red[kBlock + threadIdx.x + s];
-			red[2 * kBlock + threadIdx.x] += red[2 * kBlock + threadIdx.x + s];
+	for (unsigned word = 0; word < 3 + 2 * kTestKinds; ++word) {
+		unsigned long long a = 0;
+		for (unsigned w = threadIdx.x; w < kStatWaves; w += kBlock) a += stat[((size_t) depth * kStatWaves + w) * kStatWords + word];
+		red[threadIdx.x] = a;
+		__syncthreads();
+		for (unsigned s = kBlock / 2; s > 0; s >>= 1) {
+			if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) {
+			const unsigned long long v = red[0];
+			if (word == 0) {
+				out->per_depth[depth] = v;
+				atomicAdd(&out->trace_rays, v);
+			} else if (word == 1) {
+				out->per_depth_shadow[depth] = v;
+				atomicAdd(&out->shadow_rays, v);
+			} else if (word == 2) {
+				out->per_depth_hits[depth] = v;
+				atomicAdd(&out->shaded_hits, v);
+			} else {
+				const unsigned k = word - 3;
+				out->tests[k / kTestKinds][depth][k % kTestKinds] = v;
+			}
 		}
 		__syncthreads();
-	}
-	if (threadIdx.x == 0) {
-		out->per_depth[depth] = red[0];
-		out->per_depth_shadow[depth] = red[kBlock];
-		out->per_depth_hits[depth] = red[2 * kBlock];
-		atomicAdd(&out->trace_rays, red[0]);
-		atomicAdd(&out->shadow_rays, red[kBlock]);
-		atomicAdd(&out->shaded_hits, red[2 * kBlock]);
 	}
 }
 

@@ -32,15 +32,20 @@ def test_library_holds_gfx950_code_only(pt):
         assert other not in blob
 
 
-def test_struct_sizes_match_the_header(pt):
-    # sizes implied by the field lists of include/ptx.h
-    assert ctypes.sizeof(pt.PtxMaterial) == 13 * 4
-    assert ctypes.sizeof(pt.PtxLight) == 6 * 4
-    assert ctypes.sizeof(pt.PtxCamera) == 10 * 4
-    assert ctypes.sizeof(pt.PtxFrame) == (16 + 16 + 6 + 2) * 4
-    assert ctypes.sizeof(pt.PtxPrim) == (4 + 9 + 3 + 32) * 4
-    assert ctypes.sizeof(pt.PtxRenderParams) == 8 * 4
-    assert ctypes.sizeof(pt.PtxStats) == 5 * 8 + 3 * 16 * 8 + 2 * 3 * 16 * 8
+def test_struct_sizes_match_the_header(pt, tmp_path):
+    """The ctypes mirrors have the sizes a C compiler gives the structs of include/ptx.h (the
+    header is compiled as plain C here, which also shows that it is one)."""
+    import subprocess
+    names = ["PtxMaterial", "PtxLight", "PtxCamera", "PtxFrame", "PtxPrim", "PtxSceneDesc", "PtxRenderParams", "PtxStats"]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "ptx.h"\nint main(void) {\n' +
+                   "".join(f'printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "return 0; }\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for n in names:
+        assert ctypes.sizeof(getattr(pt, n)) == int(out[n]), n
+    assert ctypes.sizeof(pt.PtxMaterial) == 13 * 4 and ctypes.sizeof(pt.PtxPrim) == (4 + 9 + 3 + 32) * 4
 
 
 def test_no_device_means_loud_failure(pt, scenes):
