@@ -494,7 +494,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	}
 	uint64_t cap = queue_bytes / 48;
 	cap = std::min<uint64_t>(cap, 1ull << 33);  // 384 GiB: above any device; each queue is limited on its own (64 sub-queues of at most 2^25 records)
-	cap = std::max<uint64_t>(cap, 1ull << 21);  // 96 MiB: enough for one sub-queued queue per depth at the deepest tree allowed
+	cap = std::max<uint64_t>(cap, 1ull << 21);  // 96 MiB: enough for one queue per depth at the deepest tree allowed
 	cap &= ~127ull;
 	sc->work.qslots = cap;
 	{
@@ -520,7 +520,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		sc->allocs.push_back(p);
 		sc->work.stat = static_cast<unsigned long long*>(p);
 	}
-	sc->tails.assign((size_t) (kMaxBounces + 2) * kCountsPerDepth, 0u);
+	sc->tails.assign((size_t) (kMaxBounces + 2) * kMaxSeg, 0u);
 	*out = sc.release();
 	return PTX_OK;
 }
@@ -599,37 +599,55 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		if (!begin) sc->event_tag.push_back(kind * kMaxDepthSlots + (depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1));
 		return err;
 	};
-	auto queue_at = [&](uint64_t first_slot, uint64_t cap) {
-		RayQueue q;
-		q.a = M.qmem + first_slot * 3;
-		q.b = q.a + cap;
-		q.c = reinterpret_cast<float2*>(q.b + cap);
-		return q;
-	};
-	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * kCountsPerDepth; };
-	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * kCountsPerDepth; };
-	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kCountsPerDepth; };
+	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * kMaxSeg; };
+	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * kMaxSeg; };
+	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kMaxSeg; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
 	const bool rb = sc->dev.root_bvh != 0;  // (the fused kernel has no such variant: it takes the leaves one by one)
-	// persistent grids: as many blocks as the kernel can keep resident on the device, times
-	// grid_rounds so that blocks which finish early are replaced; never more than `useful`
-	auto grid_of = [&](auto kern, uint64_t useful) -> unsigned {
-		const void* key = reinterpret_cast<const void*>(kern);
-		auto it = sc->resident_blocks.find(key);
-		if (it == sc->resident_blocks.end()) {
-			int per_cu = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-			it = sc->resident_blocks.emplace(key, (unsigned) per_cu * sc->n_cus).first;
-		}
-		return (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(useful, (uint64_t) it->second * kGridRounds));
+
+	// Sizing (see the note on queues in ptx_kernels.hpp): what a launch takes of segment w of
+	// its input lands in segment w of its outputs, at most `per_ray` records per input ray in
+	// any one output queue (children: 2 with a two-child material, else 1; shadow rays: one per
+	// light; hits: 1).  So a launch may take `take` = seg_cap / per_ray records of every
+	// segment and nothing can overflow, whatever the materials do.
+	unsigned per_ray = sc->branching ? 2u : 1u;
+	if (staged) per_ray = std::max(per_ray, (unsigned) std::max(sc->dev.n_lights, 1));
+	const unsigned nqueues = std::max(max_depth, 1u);
+	// slots of one queue: the memory holds `nqueues` ray queues (+ shadow queue and hit records
+	// for the staged pipeline: 48 + 16 bytes more per slot); record indices stay below 2^31
+	const uint64_t capd = std::min<uint64_t>(M.qslots * 48 / (48ull * nqueues + (staged ? 64 : 0)), 1ull << 30);
+	// Segments = waves of every grid: kMaxSeg (four rounds of the resident workgroups) for a
+	// large render; fewer for a small one, so that every wave still gets some eight 64-sample
+	// steps of the first chunk and the steps of the deeper depths stay reasonably full; fewer,
+	// too, when the memory is small, so that a segment still takes whole steps.
+	unsigned n_seg = kMaxSeg;
+	while (n_seg > 64 && (total + 63) / 64 < (uint64_t) n_seg * 8) n_seg >>= 1;
+	while (n_seg > 4 && capd / n_seg / per_ray < 64) n_seg >>= 1;
+	const unsigned seg_cap = (unsigned) (capd / n_seg) & ~63u;
+	unsigned take = std::min((seg_cap / per_ray) & ~63u, (1u << 30) / n_seg);  // records of a segment per launch
+	if (max_depth == 0 && !staged) take = (1u << 26) / n_seg;                 // nothing is queued at all
+	if (take < 64) return fail(PTX_ERR_NOMEM, "the work memory is too small for max_ray_bounces and the number of lights of this scene");
+	const uint64_t chunk = (uint64_t) take * n_seg;  // primary samples per launch (at most 2^30)
+	const dim3 grid(n_seg / (kBlock / 64));
+	A.seg_cap = seg_cap;
+	A.n_seg = n_seg;
+	auto queue_at = [&](unsigned index) {  // queue `index` of the block: capd slots of 48 bytes, as three planes
+		RayQueue q;
+		q.a = M.qmem + (uint64_t) index * capd * 3;
+		q.b = q.a + capd;
+		q.c = reinterpret_cast<float2*>(q.b + capd);
+		return q;
 	};
-	auto launch_depth = [&](unsigned d, uint64_t useful) -> PtxStatus {
+	if (staged) {  // shadow queue and hit records behind the ray queues
+		A.shadow = queue_at(nqueues);
+		A.hits = M.qmem + ((uint64_t) nqueues + 1) * capd * 3;
+	}
+	auto launch_depth = [&](unsigned d) -> PtxStatus {
 		if (!staged) {
 			HIP_TRY(tick(0, d, true));
 			auto kern = d == 0 ? (ip ? k_bounce<true, true> : k_bounce<true, false>) : (ip ? k_bounce<false, true> : k_bounce<false, false>);
-			const unsigned grid = grid_of(kern, useful);
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(0, d, false));
 			launches += 1;
 			return PTX_OK;
@@ -643,60 +661,32 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 				return d == 0 ? (rb ? k_trace<true, true, TC> : k_trace<true, false, TC>) : (rb ? k_trace<false, true, TC> : k_trace<false, false, TC>);
 			};
 			auto kern = count_tests ? pick(TestCount{}) : pick(NoCount{});
-			hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
 		}
 		HIP_TRY(tick(0, d, false));
 		HIP_TRY(tick(1, d, true));
 		auto kern = d == 0 ? (ip ? k_shade<true, true> : k_shade<true, false>) : (ip ? k_shade<false, true> : k_shade<false, false>);
-		hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
+		hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
 			auto kern = count_tests ? (rb ? k_shadow<true, TestCount> : k_shadow<false, TestCount>) : (rb ? k_shadow<true, NoCount> : k_shadow<false, NoCount>);
-			hipLaunchKernelGGL(kern, dim3(grid_of(kern, useful)), dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
 			HIP_TRY(tick(2, d, false));
 			launches += 1;
 		}
 		launches += 2;
 		return PTX_OK;
 	};
-	// Sizing (see the note on queues in ptx_kernels.hpp): what a launch takes of sub-queue q of
-	// its input lands in sub-queue q of its outputs, at most `per_ray` records per input ray in
-	// any one output queue (children: 2 with a two-child material, else 1; shadow rays: one per
-	// light; hits: 1).  So a launch may take `take` = subcap / per_ray records of every
-	// sub-queue and nothing can overflow, whatever the materials do.
-	unsigned per_ray = sc->branching ? 2u : 1u;
-	if (staged) per_ray = std::max(per_ray, (unsigned) std::max(sc->dev.n_lights, 1));
-	// slots of one queue when the memory holds `queues` ray queues (+ shadow queue and hit
-	// records for the staged pipeline: 48 + 16 bytes more per slot)
-	auto slots_for = [&](unsigned queues) -> uint64_t {
-		uint64_t bytes = M.qslots * 48;
-		uint64_t per_slot = 48ull * queues + (staged ? 64 : 0);
-		return (bytes / per_slot) & ~(uint64_t) (kNQ * 64 - 1);
-	};
-	auto place_staged = [&](unsigned queues, uint64_t cap) {  // shadow queue and hit records behind the ray queues
-		A.shadow = queue_at((uint64_t) queues * cap, cap);
-		A.shadow_subcap = (unsigned) std::min<uint64_t>(cap / kNQ, 1u << 25);
-		A.hits = M.qmem + ((uint64_t) queues + 1) * cap * 3;
-		A.hit_subcap = (unsigned) std::min<uint64_t>(cap / kNQ, 1u << 25);
-	};
 
 	// Driving the ray tree through the queues: queue d (1..max_depth) holds the rays traced at
-	// depth d.  Every depth of a primary chunk is first launched once, back to back, each launch
-	// reading its ray counts on the device and taking at most `take` rays of every sub-queue;
-	// the host then reads the tail counters ONCE per primary chunk.  Only if some sub-queue of
-	// a depth held more than `take` rays (deep trees of two-child materials) is the remainder
-	// traced, deepest depth first - the queues below a depth are free by then - slice by slice
-	// with the counts read back after every launch (depth-first over the slices).
-	const unsigned nqueues = std::max(max_depth, 1u);
-	const uint64_t capd = slots_for(nqueues);
-	const unsigned subcap = (unsigned) std::min<uint64_t>(capd / kNQ, 1u << 25);  // 64 sub-queues of it stay below 2^31 records
-	unsigned take = std::min((subcap / per_ray) & ~63u, 1u << 24);
-	if (max_depth == 0 && !staged) take = 1u << 20;  // nothing is queued at all
-	if (take < 64) return fail(PTX_ERR_NOMEM, "the work memory is too small for max_ray_bounces and the number of lights of this scene");
-	const unsigned chunk = take * kNQ;  // primary samples per launch (at most 2^30)
-	if (staged) place_staged(nqueues, capd);
-	A.out_subcap = A.in_subcap = subcap;
+	// depth d.  Every depth of a primary chunk is first launched once, back to back, each wave
+	// reading its segment's count on the device and taking at most `take` rays of it; the host
+	// then reads the counts ONCE per primary chunk.  Only if some segment of a depth held more
+	// than `take` rays (deep trees of two-child materials) is the remainder traced, deepest
+	// depth first - the queues below a depth are free by then - slice by slice with the counts
+	// read back after every launch (depth-first over the slices).  Every wave of a launch
+	// writes its counts, so nothing needs clearing in between.
 	unsigned* tails = sc->tails.data();
 	auto set_depth = [&](unsigned d, unsigned first, unsigned n_take) {
 		const bool last = (d == max_depth);
@@ -706,27 +696,24 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		A.in_take = n_take;
 		A.in_count = count_of(d);
 		A.out_count = count_of(d + 1);
-		if (d > 0) A.in = queue_at((uint64_t) (d - 1) * capd, capd);
-		A.out = queue_at((uint64_t) (last ? 0 : d) * capd, capd);
+		if (d > 0) A.in = queue_at(d - 1);
+		A.out = queue_at(last ? 0 : d);
 	};
-	auto fullest = [&](const unsigned* t) {  // records in the fullest sub-queue
+	auto fullest = [&](const unsigned* t) {  // records in the fullest segment
 		unsigned m = 0;
-		for (unsigned k = 0; k < kNQ; ++k) m = std::max(m, std::min(t[(size_t) k * kCountPad], subcap));
+		for (unsigned k = 0; k < n_seg; ++k) m = std::max(m, std::min(t[k], seg_cap));
 		return m;
 	};
-	// records [first0, n) of every sub-queue of queue d in slices; each slice's children go to queue
+	// records [first0, n) of every segment of queue d in slices; each slice's children go to queue
 	// d+1 and are finished (recursively) before the next slice overwrites that queue
 	auto run = [&](auto&& self, unsigned d, unsigned first0, unsigned n) -> PtxStatus {
 		for (uint64_t first = first0; first < n; first += take) {
 			const bool last = (d == max_depth);
-			if (!last) HIP_TRY(hipMemsetAsync(count_of(d + 1), 0, kCountsPerDepth * sizeof(unsigned), stream));
-			if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
-			if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(d), 0, kCountsPerDepth * sizeof(unsigned), stream));
 			set_depth(d, (unsigned) first, take);
-			PtxStatus ls = launch_depth(d, ~0ull);
+			PtxStatus ls = launch_depth(d);
 			if (ls != PTX_OK) return ls;
 			if (last) continue;
-			HIP_TRY(hipMemcpyAsync(tails, count_of(d + 1), kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipMemcpyAsync(tails, count_of(d + 1), n_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipStreamSynchronize(stream));
 			const unsigned m = fullest(tails);
 			if (m) {
@@ -737,23 +724,19 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		return PTX_OK;
 	};
 	for (uint64_t first = 0; first < total; first += chunk) {
-		const unsigned cnt = (unsigned) std::min<uint64_t>(chunk, total - first);
-		if (max_depth > 0) HIP_TRY(hipMemsetAsync(M.counts, 0, (size_t) (max_depth + 2) * kCountsPerDepth * sizeof(unsigned), stream));
-		if (staged) HIP_TRY(hipMemsetAsync(shadow_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
-		if (staged) HIP_TRY(hipMemsetAsync(hit_count_of(0), 0, (size_t) (max_depth + 1) * kCountsPerDepth * sizeof(unsigned), stream));
 		A.first_pix = (unsigned) (first / ns);
 		A.first_s = (unsigned) (first % ns);
-		A.batch = cnt;
+		A.batch = (unsigned) std::min<uint64_t>(chunk, total - first);
 		for (unsigned d = 0; d <= max_depth; ++d) {
 			set_depth(d, 0, take);
-			PtxStatus ls = launch_depth(d, d == 0 ? (cnt + kBlock - 1) / kBlock : ~0ull);
+			PtxStatus ls = launch_depth(d);
 			if (ls != PTX_OK) return ls;
 		}
 		if (max_depth == 0) continue;
-		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * kCountsPerDepth * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * kMaxSeg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		unsigned held[kMaxBounces + 2] = {0};
-		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * kCountsPerDepth);
+		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * kMaxSeg);
 		for (unsigned d = max_depth; d >= 1; --d) {
 			if (held[d] <= take) continue;
 			PtxStatus rst = run(run, d, take, held[d]);

@@ -21,16 +21,9 @@ constexpr int kStack = 30;  // entries per lane; a BVH of depth d needs d - 1 (k
 static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
 constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
 constexpr unsigned kMaxBounces = 63;
-// A ray queue is cut into kNQ sub-queues, each with its own tail counter on its own 128-B
-// line.  A wave appends the children of its k-th 64-ray step to sub-queue (k mod kNQ) with
-// one returning atomic.  With ONE tail word every wave of the chip queues up behind the same
-// address (adds to one word retire one at a time, roughly 10 ns each, which made the append
-// the most expensive step of a bounce); spread over 64 words they proceed in parallel, and
-// because consecutive steps go to consecutive sub-queues every sub-queue fills evenly.
-constexpr unsigned kNQ = 64;
-constexpr unsigned kCountPad = 32;  // words between two tail counters
-constexpr unsigned kCountsPerDepth = kNQ * kCountPad;
-constexpr size_t kCountBytes = (size_t) 3 * (kMaxBounces + 2) * kCountsPerDepth * sizeof(unsigned);  // ray-queue tails, shadow-queue tails, hit-list tails
+// A queue is cut into segments, one per wave of a launch (see the note on queues at the kernels).
+constexpr unsigned kMaxSeg = 16384;  // most segments = waves of a grid: four rounds of the workgroups an MI355X keeps resident
+constexpr size_t kCountBytes = (size_t) 3 * (kMaxBounces + 2) * kMaxSeg * sizeof(unsigned);  // per depth: ray, shadow-ray and hit counts of every segment
 
 // ---------------------------------------------------------------------------
 // device scene
@@ -868,28 +861,30 @@ __device__ __forceinline__ void make_primary(const DevCamera& cam, unsigned pixe
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-// Queues.  A queue (rays of one depth, shadow rays, hit records) is cut into kNQ sub-queues
-// with separate tail counters.  The work of a launch is dealt to the waves in UNITS of 64
-// records: unit u is records [64 k, 64 k + 64) of sub-queue q, with q = u mod kNQ and
-// k = u / kNQ (depth 0, where the rays are generated: samples [64 u, 64 u + 64) of the batch).
-// Everything a unit produces - hit records, child rays, shadow rays - goes to sub-queue q of
-// the respective output queue.  So:
-//   * a record's place follows from (q, k, lane) alone: no prefix sums over the sub-queues, no
-//     search, and a hit record names its ray by its slot in the queue;
-//   * sub-queue q of an output holds at most (records taken from sub-queue q of the input) x
-//     (records one input can produce), whatever the waves do in between (parking rays, walking
-//     them later): the host sizes `in_take` from that and nothing can overflow;
-//   * the 64 sub-queues stay equally full (consecutive 64-sample steps of the image go to
-//     consecutive sub-queues), which is what keeps the units of a launch equally long.
+// Queues.  Every queue (the rays of one depth, the shadow rays, the hit records) is cut into
+// n_seg SEGMENTS of seg_cap slots, and segment w belongs to wave w of every launch: a grid is
+// exactly n_seg waves.  Wave w of the closest-hit kernel reads ray segment w and writes hit
+// segment w; wave w of the shading kernel reads hit segment w (and, through the slot a hit
+// record names, ray segment w) and writes ray segment w of the next depth and shadow segment
+// w; wave w of the shadow kernel reads shadow segment w.  So
+//   * a wave appends by counting in a register and stores the count once, at its end: no
+//     atomics on queue tails (one returning atomic per 64-record step and output queue was
+//     what the shading kernel spent most of its time waiting for: doubling them doubled its
+//     time), no prefix sums, no search: a record's place is (segment, index);
+//   * segment w of an output holds at most (records taken from segment w of the input) x
+//     (records one input can produce), whatever the wave does in between (parking rays,
+//     walking them later): the host sizes `in_take` from that and nothing can overflow;
+//   * the segments stay about equally full: the 64-sample steps of a batch are dealt to the
+//     waves round-robin, so every wave gets an even sample of the image.
 struct BounceArgs {
 	DevScene S;
 	DevCamera cam;
 	RayQueue in, out;
-	const unsigned* in_count;  // kNQ tail counters of `in` (depth > 0), kCountPad words apart
-	unsigned* out_count;       // kNQ tail counters of `out`
-	unsigned out_subcap;       // slots per sub-queue of `out`
-	unsigned in_subcap;
-	unsigned in_first;         // depth > 0: the launch takes records [in_first, in_first + in_take) of every sub-queue of `in`
+	const unsigned* in_count;  // records in every segment of `in` (depth > 0), one word per segment
+	unsigned* out_count;       // records in every segment of `out`: every wave of the launch writes its word
+	unsigned seg_cap;          // slots per segment (the same for every queue)
+	unsigned n_seg;            // segments = waves of the grid
+	unsigned in_first;         // depth > 0: the launch takes records [in_first, in_first + in_take) of every segment of `in`
 	unsigned in_take;          // (0 = all from in_first on)
 	unsigned first_pix, first_s;  // depth 0: the batch starts at sample first_s (< ns) of this render's range in pixel first_pix
 	double inv_ns;             // 1.0 / ns
@@ -902,45 +897,42 @@ struct BounceArgs {
 	unsigned long long* stat;  // work counters, spread over kStatWaves slots
 	// staged pipeline only
 	RayQueue shadow;           // a = (o.xyz, bits(pixel))  b = (contribution rgb, bits(light)); plane c unused (32 B per shadow ray)
-	unsigned* shadow_count;    // kNQ tail counters of `shadow`
-	unsigned shadow_subcap;
-	float4* hits;              // hit list of the launch, sub-queued like the ray queues: (t, bits(prim id), bits(where), bits(ray))
+	unsigned* shadow_count;
+	float4* hits;              // hit records: (t, bits(prim id), bits(where), bits(ray))
 	                           // ray = the sample's index in the batch (depth 0) or the ray's slot in `in`
-	unsigned* hit_count;       // kNQ tail counters of `hits`
-	unsigned hit_subcap;
+	unsigned* hit_count;
 };
 
-// Records the launch takes of every sub-queue -> cnt[0..kNQ) in LDS (cnt[kNQ] = their maximum);
-// returns the number of units.  All threads of the workgroup must call it.
-__device__ __forceinline__ unsigned sub_counts(const unsigned* count, unsigned subcap, unsigned first, unsigned take, unsigned* cnt) {
-	if (threadIdx.x < 64) {
-		unsigned c = min(count[threadIdx.x * kCountPad], subcap);
-		c = c > first ? c - first : 0;
-		if (take) c = min(c, take);
-		cnt[threadIdx.x] = c;
-		unsigned m = c;
-		for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned) __shfl_xor((int) m, off));
-		if (threadIdx.x == 0) cnt[kNQ] = m;
-	}
-	__syncthreads();
-	return ((cnt[kNQ] + 63) >> 6) * kNQ;
+// this wave's number: the same in every lane, and known to the compiler to be (scalar registers, scalar loads)
+__device__ __forceinline__ unsigned wave_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)); }
+
+// records of segment `wave` of a queue that a launch takes, given the segment's count
+__device__ __forceinline__ unsigned taken(unsigned count, unsigned seg_cap, unsigned first, unsigned take) {
+	unsigned c = min(count, seg_cap);
+	c = c > first ? c - first : 0;
+	return take ? min(c, take) : c;
 }
-// units of a launch: the primary batch, or what the launch takes of queue `in`
+// 64-record steps of wave `wave` in a launch; n = records it takes of its segment (depth > 0)
 template <bool PRIMARY>
-__device__ __forceinline__ unsigned launch_units(const BounceArgs& A, unsigned* cnt) {
-	if (PRIMARY) return (A.batch + 63) >> 6;
-	return sub_counts(A.in_count, A.in_subcap, A.in_first, A.in_take, cnt);
-}
-// lane's record of unit u: `ref` = sample index in the batch (depth 0) or slot in `in`; false = no record
-template <bool PRIMARY>
-__device__ __forceinline__ bool unit_record(const BounceArgs& A, const unsigned* cnt, unsigned u, unsigned lane, unsigned& ref) {
+__device__ __forceinline__ unsigned wave_steps(const BounceArgs& A, unsigned wave, unsigned& n) {
 	if (PRIMARY) {
-		ref = u * 64 + lane;
+		const unsigned units = (A.batch + 63) >> 6;  // dealt round-robin: wave w takes units w, w + n_seg, ...
+		n = 0;
+		return wave < units ? (units - wave + A.n_seg - 1) / A.n_seg : 0;
+	}
+	n = taken(A.in_count[wave], A.seg_cap, A.in_first, A.in_take);
+	return (n + 63) >> 6;
+}
+// lane's record in step k: `ref` = sample index in the batch (depth 0) or slot in `in`; false = no record
+template <bool PRIMARY>
+__device__ __forceinline__ bool step_record(const BounceArgs& A, unsigned wave, unsigned n, unsigned k, unsigned lane, unsigned& ref) {
+	if (PRIMARY) {
+		ref = (wave + k * A.n_seg) * 64 + lane;
 		return ref < A.batch;
 	}
-	const unsigned q = u & (kNQ - 1), r = (u >> 6) * 64 + lane;
-	ref = q * A.in_subcap + A.in_first + r;
-	return r < cnt[q];
+	const unsigned r = k * 64 + lane;
+	ref = wave * A.seg_cap + A.in_first + r;
+	return r < n;
 }
 
 // the input ray behind `ref`: generated (depth 0, framework/renderer.cpp:76-82) or read from `in`
@@ -963,58 +955,34 @@ __device__ __forceinline__ void input_ray(const BounceArgs& A, unsigned ref, f3&
 	}
 }
 
-// wave64 ballot compaction of up to two records per lane into sub-queue q of a queue: the
-// records of a lane stay adjacent, the wave takes its slots with ONE returning atomic.  The
-// two halves are separate calls so that a kernel can put independent work between asking
-// for the slots and needing them (the atomic's round trip to the memory side is long).
-struct Reserved {
-	unsigned slot0;  // lane 0 only until emit_write broadcasts it
-	unsigned q;
-	unsigned long long m1, m2;
-};
-__device__ __forceinline__ Reserved emit_reserve(unsigned* tails, unsigned q, bool live1, bool live2) {
-	Reserved R;
-	R.m1 = __ballot(live1);
-	R.m2 = __ballot(live2);
-	R.slot0 = 0;
-	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
-	R.q = q;
-	if (total && lane_id() == 0) R.slot0 = atomicAdd(tails + q * kCountPad, total);
-#ifdef EXP_DOUBLE_RESERVE
-	if (total && lane_id() == 0) R.slot0 += atomicAdd(tails + q * kCountPad + 16, 0u) & 0u;
-#endif
-	return R;
-}
+// wave64 ballot compaction of up to two records per lane into the wave's own segment of a
+// queue: the records of a lane stay adjacent; `tail` (the same in every lane) is the wave's
+// count so far.  A record that would not fit is dropped and flagged (the host's sizing rules
+// that out; kept as a tripwire).
 template <bool WITH_C = true>
-__device__ __forceinline__ void emit_write(const RayQueue& Q, unsigned subcap, const Reserved& R, bool live1, const float4 r1[3],
-                                           bool live2, const float4 r2[3], Counters* counters) {
-	const unsigned total = __builtin_popcountll(R.m1) + __builtin_popcountll(R.m2);
+__device__ __forceinline__ void emit_pair(const RayQueue& Q, size_t seg_base, unsigned seg_cap, unsigned& tail, bool live1, const float4 r1[3],
+                                          bool live2, const float4 r2[3], Counters* counters) {
+	const unsigned long long m1 = __ballot(live1), m2 = __ballot(live2);
+	const unsigned total = __builtin_popcountll(m1) + __builtin_popcountll(m2);
 	if (!total) return;
 	const unsigned lane = lane_id();
-	const unsigned q = R.q;
-	const unsigned slot0 = __shfl(R.slot0, 0);
-	unsigned long long lt = lanes_below(lane);
-	unsigned my = slot0 + __builtin_popcountll(R.m1 & lt) + __builtin_popcountll(R.m2 & lt);
-	const size_t qbase = (size_t) q * subcap;
+	const unsigned long long lt = lanes_below(lane);
+	unsigned my = tail + __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
 	if (live1) {
-		if (my < subcap) {
-			Q.a[qbase + my] = r1[0];
-			Q.b[qbase + my] = r1[1];
-			if (WITH_C) Q.c[qbase + my] = make_float2(r1[2].x, r1[2].y);
+		if (my < seg_cap) {
+			Q.a[seg_base + my] = r1[0];
+			Q.b[seg_base + my] = r1[1];
+			if (WITH_C) Q.c[seg_base + my] = make_float2(r1[2].x, r1[2].y);
 		}
 		++my;
 	}
-	if (live2 && my < subcap) {
-		Q.a[qbase + my] = r2[0];
-		Q.b[qbase + my] = r2[1];
-		if (WITH_C) Q.c[qbase + my] = make_float2(r2[2].x, r2[2].y);
+	if (live2 && my < seg_cap) {
+		Q.a[seg_base + my] = r2[0];
+		Q.b[seg_base + my] = r2[1];
+		if (WITH_C) Q.c[seg_base + my] = make_float2(r2[2].x, r2[2].y);
 	}
-	if (lane == 0 && slot0 + total > subcap) atomicAdd(&counters->overflow, 1ull);  // (the host's sizing rules this out; kept as a tripwire)
-}
-__device__ __forceinline__ void emit_pair(const RayQueue& Q, unsigned* tails, unsigned subcap, unsigned q, bool live1,
-                                          const float4 r1[3], bool live2, const float4 r2[3], Counters* counters) {
-	const Reserved R = emit_reserve(tails, q, live1, live2);
-	emit_write(Q, subcap, R, live1, r1, live2, r2, counters);
+	tail += total;
+	if (lane == 0 && tail > seg_cap) atomicAdd(&counters->overflow, 1ull);
 }
 
 __device__ __forceinline__ void pack_child(const Child& c, unsigned pix, float4 r[3]) {
@@ -1044,18 +1012,18 @@ __device__ __forceinline__ void stat_add_tests<NoCount>(unsigned long long*, int
 template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned cnt[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned units = launch_units<PRIMARY>(A, cnt);
-	const unsigned waves_per_block = kBlock / 64;
-	const unsigned wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * waves_per_block;
+	const unsigned wave = wave_id();
+	unsigned n;
+	const unsigned steps = wave_steps<PRIMARY>(A, wave, n);
+	const size_t seg_base = (size_t) wave * A.seg_cap;
+	unsigned n_out = 0;
 	unsigned cnt_trace = 0, cnt_shadow = 0, cnt_hits = 0;
 
-	for (unsigned u = wave; u < units; u += n_waves) {
+	for (unsigned k = 0; k < steps; ++k) {
 		unsigned ref;
-		const bool active = unit_record<PRIMARY>(A, cnt, u, lane, ref);
+		const bool active = step_record<PRIMARY>(A, wave, n, k, lane, ref);
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
 		if (active) input_ray<PRIMARY>(A, ref, o, d, w, pix);
@@ -1078,8 +1046,9 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 		float4 r1[3], r2[3];
 		pack_child(refl, pix, r1);
 		pack_child(refr, pix, r2);
-		emit_pair(A.out, A.out_count, A.out_subcap, u & (kNQ - 1), refl.live, r1, refr.live, r2, A.counters);
+		emit_pair(A.out, seg_base, A.seg_cap, n_out, refl.live, r1, refr.live, r2, A.counters);
 	}
+	if (lane == 0) A.out_count[wave] = n_out;
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 0, cnt_trace);
 	stat_add(st, 1, cnt_shadow);
@@ -1102,32 +1071,27 @@ constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from whi
 template <bool PRIMARY, bool RB, class TC>
 __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned cnt[kNQ + 1];
 	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
 	int* stk = lds_stack + threadIdx.x;
 	volatile float4* ring = ring_mem + (threadIdx.x >> 6) * kRing;
 	const unsigned lane = lane_id();
-	const unsigned units = launch_units<PRIMARY>(A, cnt);
-	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * (kBlock / 64);
+	const unsigned wave = wave_id();
+	unsigned n;
+	const unsigned steps = wave_steps<PRIMARY>(A, wave, n);
+	float4* const my_hits = A.hits + (size_t) wave * A.seg_cap;
+	unsigned n_hit = 0;
 	unsigned cnt_trace = 0;
 	TC tc;
-	unsigned parked = 0, parked_q = 0;  // the same in every lane; the parked rays all come from sub-queue parked_q
-	// the hit records of the lanes with `hit`, compacted, into sub-list q (keeping them in
-	// registers until the atomic's answer has arrived, a step later, was measured: no gain)
-	auto emit = [&](unsigned q, bool hit, const Hit& h, unsigned ref) {
+	unsigned parked = 0;  // the same in every lane
+	// the hit records of the lanes with `hit`, compacted, appended to the wave's hit segment
+	auto emit = [&](bool hit, const Hit& h, unsigned ref) {
 		const unsigned long long m = __ballot(hit);
 		if (!m) return;
-		const unsigned total = __builtin_popcountll(m);
-		unsigned slot0 = 0;
-		if (lane == 0) slot0 = atomicAdd(A.hit_count + q * kCountPad, total);
-		slot0 = __shfl(slot0, 0);
-		const unsigned my = slot0 + __builtin_popcountll(m & lanes_below(lane));
+		const unsigned my = n_hit + __builtin_popcountll(m & lanes_below(lane));
 		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
 		const int where = h.frame == 0 ? h.slot : -h.frame;
-		if (hit && my < A.hit_subcap)
-			A.hits[(size_t) q * A.hit_subcap + my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(ref));
-		if (lane == 0 && slot0 + total > A.hit_subcap) atomicAdd(&A.counters->overflow, 1ull);  // (cannot happen: a ray leaves at most one hit)
+		if (hit && my < A.seg_cap) my_hits[my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(ref));
+		n_hit += __builtin_popcountll(m);  // (never beyond seg_cap: a ray leaves at most one hit)
 	};
 	// the mesh walks of the `count` most recently parked rays
 	auto walk_parked = [&](unsigned count) {
@@ -1150,15 +1114,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			closest_frames<false>(A.S, o, d, pre, 0u, stk, h, tc);
 		}
 		parked -= count;
-		emit(parked_q, h.id >= 0, h, ref);
+		emit(h.id >= 0, h, ref);
 	};
-	for (unsigned u = wave; u < units; u += n_waves) {
-		const unsigned q = u & (kNQ - 1);
-		// (a grid of a multiple of 16 workgroups keeps a wave on one sub-queue; otherwise the
-		// rays parked so far are walked before the wave moves to another)
-		if (parked && q != parked_q) walk_parked(parked);
+	for (unsigned k = 0; k < steps; ++k) {
 		unsigned ref;
-		const bool active = unit_record<PRIMARY>(A, cnt, u, lane, ref);
+		const bool active = step_record<PRIMARY>(A, wave, n, k, lane, ref);
 		Hit h;
 		h.id = -1;
 		h.frame = 0;
@@ -1183,7 +1143,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h, tc);
 			park = false;
 		}
-		emit(q, h.id >= 0 && !park, h, ref);
+		emit(h.id >= 0 && !park, h, ref);
 		if (np && !walk_now) {
 			if (parked + np > kRing) walk_parked(parked < 64 ? parked : 64);
 			if (park) {
@@ -1194,11 +1154,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 				rq->w = __uint_as_float(ref);
 			}
 			parked += np;
-			parked_q = q;
 			if (parked >= 64) walk_parked(64);
 		}
 	}
 	if (parked) walk_parked(parked);
+	if (lane == 0) A.hit_count[wave] = n_hit;
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 0, cnt_trace);
 	stat_add_tests(st, 3, tc);
@@ -1206,26 +1166,25 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 
 template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) {
-	__shared__ unsigned cnt[kNQ + 1];
-	const unsigned units = sub_counts(A.hit_count, A.hit_subcap, 0, 0, cnt);
 	const unsigned lane = lane_id();
-	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * (kBlock / 64);
+	const unsigned wave = wave_id();
+	const unsigned n = min(A.hit_count[wave], A.seg_cap);
+	const unsigned steps = (n + 63) >> 6;
+	const size_t seg_base = (size_t) wave * A.seg_cap;
+	const float4* const my_hits = A.hits + seg_base;
+	unsigned n_out = 0, n_shadow = 0;
 	unsigned cnt_shadow = 0, cnt_hits = 0;
-	// the hit record of a unit is fetched one unit ahead, so that its trip from memory runs
-	// beside the previous unit's work instead of in front of this unit's
-	auto fetch_hit = [&](unsigned u) {
-		const unsigned q = u & (kNQ - 1), r = (u >> 6) * 64 + lane;
-		return r < cnt[q] ? A.hits[(size_t) q * A.hit_subcap + r] : make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
-	};
-	unsigned u = wave;
-	float4 hr_next = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
-	if (u < units) hr_next = fetch_hit(u);
-	for (; u < units; u += n_waves) {
-		const unsigned q = u & (kNQ - 1);
+	// the hit record of a step is fetched one step ahead, so that its trip from memory runs
+	// beside the previous step's work instead of in front of this step's
+	const float4 none = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
+	float4 hr_next = lane < n ? my_hits[lane] : none;
+	for (unsigned k = 0; k < steps; ++k) {
 		const float4 hr = hr_next;
 		const bool hit = __float_as_int(hr.y) >= 0;
-		if (u + n_waves < units) hr_next = fetch_hit(u + n_waves);
+		{
+			const unsigned r = (k + 1) * 64 + lane;
+			hr_next = r < n ? my_hits[r] : none;
+		}
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
 		Surface sf;
@@ -1255,10 +1214,6 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 			contrib = cmul(w, (cmul(ld3(A.S.ambient), M.ka) * M.opacity) * k1);
 			++cnt_hits;
 		}
-		// the slots of the child rays are asked for first and used last: the light terms, the
-		// shadow records and the accumulation all fit inside that atomic's round trip
-		const Reserved rc = emit_reserve(A.out_count, q, refl.live, refr.live);
-		bool accumulated = false;
 		// one shadow ray per light whose term can add something; its record carries the finished
 		// contribution weight * ((diffuse + specular) * opacity * k1)
 		for (int l = 0; l < A.S.n_lights; ++l) {
@@ -1276,16 +1231,18 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 				r[2] = r[1];
 			}
 			if (want) ++cnt_shadow;
-			const Reserved rs = emit_reserve(A.shadow_count, q, want, false);
-			if (!accumulated) accumulate(A.accum, pix, contrib, hit);
-			accumulated = true;
-			emit_write<false>(A.shadow, A.shadow_subcap, rs, want, r, false, r, A.counters);
+			emit_pair<false>(A.shadow, seg_base, A.seg_cap, n_shadow, want, r, false, r, A.counters);
 		}
-		if (!accumulated) accumulate(A.accum, pix, contrib, hit);
 		float4 r1[3], r2[3];
 		pack_child(refl, pix, r1);
 		pack_child(refr, pix, r2);
-		emit_write(A.out, A.out_subcap, rc, refl.live, r1, refr.live, r2, A.counters);
+		emit_pair(A.out, seg_base, A.seg_cap, n_out, refl.live, r1, refr.live, r2, A.counters);
+		// (last in the step: a later load of this wave cannot complete before an earlier atomic has)
+		accumulate(A.accum, pix, contrib, hit);
+	}
+	if (lane == 0) {
+		A.out_count[wave] = n_out;
+		A.shadow_count[wave] = n_shadow;
 	}
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 1, cnt_shadow);
@@ -1297,21 +1254,21 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 template <bool RB, class TC>
 __global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ unsigned cnt[kNQ + 1];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned units = sub_counts(A.shadow_count, A.shadow_subcap, 0, 0, cnt);
-	const unsigned wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	const unsigned n_waves = gridDim.x * (kBlock / 64);
+	const unsigned wave = wave_id();
+	const unsigned n = min(A.shadow_count[wave], A.seg_cap);
+	const unsigned steps = (n + 63) >> 6;
+	const size_t seg_base = (size_t) wave * A.seg_cap;
 	TC tc;
-	for (unsigned u = wave; u < units; u += n_waves) {
-		const unsigned q = u & (kNQ - 1), r = (u >> 6) * 64 + lane;
-		const bool active = r < cnt[q];
+	for (unsigned k = 0; k < steps; ++k) {
+		const unsigned r = k * 64 + lane;
+		const bool active = r < n;
 		unsigned pix = 0;
 		f3 c = {0, 0, 0};
 		bool lit = false;
 		if (active) {
-			const size_t j = (size_t) q * A.shadow_subcap + r;
+			const size_t j = seg_base + r;
 			const float4 a = A.shadow.a[j], b = A.shadow.b[j];
 			pix = __float_as_uint(a.w);
 			c = mk(b.x, b.y, b.z);
