@@ -102,7 +102,7 @@ def _load(name):
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} is missing: build it with `make -C path-tracer_amd/csrc` (there is no fallback path)")
-        _libs[name] = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        _libs[name] = C.CDLL(path)
     return _libs[name]
 
 
@@ -111,7 +111,7 @@ def ptx_lib():
         if _ptx_path is not None:
             if not os.path.exists(_ptx_path):
                 raise FileNotFoundError(_ptx_path)
-            _libs["ptx"] = C.CDLL(_ptx_path, mode=C.RTLD_GLOBAL)
+            _libs["ptx"] = C.CDLL(_ptx_path)
         else:
             _libs["ptx"] = _load("libptx.so")
     L = _libs["ptx"]

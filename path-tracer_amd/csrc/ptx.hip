@@ -85,11 +85,11 @@ bool is_identity(const float* m) {
 struct WorkMem {
 	float4* qmem = nullptr;        // cut per render into ray queues, a shadow queue and a hit list
 	uint64_t qslots = 0;           // its size in 48-byte slots
-	unsigned* counts = nullptr;    // tail counters: per depth 64 sub-queue tails, 128 B apart, for rays, shadow rays and hits (kCountBytes)
+	unsigned* counts = nullptr;    // records per segment: 3 x (kMaxBounces + 2) rows (rays, shadow rays, hits per depth) of max_seg words
+	unsigned max_seg = 0;          // most segments (= waves of a grid) a render may use with this memory
 	Counters* counters = nullptr;  // kCounterBytes
 	unsigned long long* stat = nullptr;  // kStatBytes
 };
-constexpr unsigned kGridRounds = 4;  // a persistent grid holds this many times the blocks the device keeps resident (2..6 measured flat)
 
 struct PtxScene {
 	int device = 0;
@@ -102,8 +102,6 @@ struct PtxScene {
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
 	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
-	unsigned n_cus = 0;
-	std::map<const void*, unsigned> resident_blocks;  // per kernel: blocks the device keeps resident at once
 	int profiling = 0;       // 0 off, 1 events around every launch, 2 events + the counting twins of the traversal kernels
 	std::vector<hipEvent_t> events;      // pairs, reused from call to call
 	std::vector<unsigned> event_tag;     // kernel kind and depth of pair k
@@ -245,7 +243,6 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	sc->n_prims = D->n_prims;
 	sc->n_frames = D->n_frames;
 	sc->grid = prop.multiProcessorCount * 8;
-	sc->n_cus = (unsigned) prop.multiProcessorCount;
 
 	// ---- materials, lights
 	std::vector<float4> mats((size_t) D->n_materials * 4);
@@ -510,9 +507,10 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	}
 	{
 		void* p = nullptr;
-		if (hipMalloc(&p, kCountBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
+		if (hipMalloc(&p, count_bytes(kMaxSeg)) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
 		sc->work.counts = static_cast<unsigned*>(p);
+		sc->work.max_seg = kMaxSeg;
 		if (hipMalloc(&p, kCounterBytes) != hipSuccess) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_NOMEM, "counter allocation failed"); }
 		sc->allocs.push_back(p);
 		sc->work.counters = static_cast<Counters*>(p);
@@ -599,9 +597,9 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		if (!begin) sc->event_tag.push_back(kind * kMaxDepthSlots + (depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1));
 		return err;
 	};
-	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * kMaxSeg; };
-	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * kMaxSeg; };
-	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * kMaxSeg; };
+	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * M.max_seg; };
+	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * M.max_seg; };
+	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * M.max_seg; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
 	const bool rb = sc->dev.root_bvh != 0;  // (the fused kernel has no such variant: it takes the leaves one by one)
@@ -621,7 +619,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	// large render; fewer for a small one, so that every wave still gets some eight 64-sample
 	// steps of the first chunk and the steps of the deeper depths stay reasonably full; fewer,
 	// too, when the memory is small, so that a segment still takes whole steps.
-	unsigned n_seg = kMaxSeg;
+	unsigned n_seg = M.max_seg;
 	while (n_seg > 64 && (total + 63) / 64 < (uint64_t) n_seg * 8) n_seg >>= 1;
 	while (n_seg > 4 && capd / n_seg / per_ray < 64) n_seg >>= 1;
 	const unsigned seg_cap = (unsigned) (capd / n_seg) & ~63u;
@@ -733,10 +731,10 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 			if (ls != PTX_OK) return ls;
 		}
 		if (max_depth == 0) continue;
-		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * kMaxSeg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * M.max_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		unsigned held[kMaxBounces + 2] = {0};
-		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * kMaxSeg);
+		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * M.max_seg);
 		for (unsigned d = max_depth; d >= 1; --d) {
 			if (held[d] <= take) continue;
 			PtxStatus rst = run(run, d, take, held[d]);

@@ -23,7 +23,7 @@ constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper l
 constexpr unsigned kMaxBounces = 63;
 // A queue is cut into segments, one per wave of a launch (see the note on queues at the kernels).
 constexpr unsigned kMaxSeg = 16384;  // most segments = waves of a grid: four rounds of the workgroups an MI355X keeps resident
-constexpr size_t kCountBytes = (size_t) 3 * (kMaxBounces + 2) * kMaxSeg * sizeof(unsigned);  // per depth: ray, shadow-ray and hit counts of every segment
+constexpr size_t count_bytes(unsigned max_seg) { return (size_t) 3 * (kMaxBounces + 2) * max_seg * sizeof(unsigned); }  // per depth: ray, shadow-ray and hit counts of every segment
 
 // ---------------------------------------------------------------------------
 // device scene
