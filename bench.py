@@ -163,9 +163,14 @@ def measured_traffic(args, queue_gib, kernel):
             continue
         if abs(float(w.get("queue_gib", -1)) - queue_gib) > 0.5:
             continue
-        k = t.get(kernel)
-        if k and "hbm_bytes_per_launch" in k:
-            return k["hbm_bytes_per_launch"]
+        # `kernel` is a name like k_shade<false>; the symbols carry more template arguments
+        # (k_shade<false, true>), of which one variant runs on a given scene
+        stem = kernel[:-1] if kernel.endswith(">") else kernel
+        rows = [v for name, v in t.items() if (name == kernel or name.startswith(stem + ",") or (not kernel.endswith(">") and name.startswith(stem + "<"))) and "TestCount" not in name
+                and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+        if rows:
+            n = sum(r["launches"] for r in rows)
+            return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n
     return None
 
 

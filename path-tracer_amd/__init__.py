@@ -9,6 +9,10 @@ The work is done by two in-tree shared libraries built by ``make -C path-tracer_
 
 There is no CPU implementation behind this module: if the libraries are missing, or no
 gfx950 device is present, the calls raise.
+
+A process that also uses torch should import torch BEFORE the first call into this module:
+torch's wheel brings a HIP runtime of its own with the system runtime's soname, and whichever
+is loaded first serves both; loaded the other way round the process holds two runtimes.
 """
 import ctypes as C
 import os
@@ -158,8 +162,60 @@ def host_lib():
     H.pth_prim_path.argtypes = [C.c_void_p, C.c_int]
     H.pth_tree_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     H.pth_render_file.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, C.c_void_p, C.POINTER(C.c_double)]
+    H.pth_shape_matrices.restype = None
+    H.pth_shape_matrices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     H._typed = True
     return H
+
+
+def shape_matrices(xforms):
+    """World matrix and inverse (column-major float32[16] each) of a Shape after the transforms
+    `xforms` = [[op, a, b, c], ...] (1 translate, 2 rotate in radians, 3 scale), formed by the host
+    mirror's Shape::translate / rotate / scale."""
+    xf = np.ascontiguousarray(np.array(xforms, np.float32).reshape(-1, 4))
+    w, wi = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    host_lib().pth_shape_matrices(_ptr(xf), xf.shape[0], _ptr(w), _ptr(wi))
+    return w, wi
+
+
+class DescScene:
+    """A scene described directly as PtxSceneDesc arrays (no scene file): `prims` is a list of
+    dicts(kind, p, world, world_inv[, normal, material, levels_in]) under an untransformed root
+    whose bounds are `bounds` (min xyz, max xyz).  Stands where a HostScene does for DeviceScene."""
+
+    def __init__(self, prims, bounds=((-1e30,) * 3, (1e30,) * 3), materials=None, lights=(), ambient=(0, 0, 0), camera=None):
+        ident = np.eye(4, dtype=np.float32).reshape(-1)
+        self._frames = (PtxFrame * 1)()
+        f = self._frames[0]
+        f.world[:] = ident
+        f.world_inv[:] = ident
+        f.bounds_min[:] = bounds[0]
+        f.bounds_max[:] = bounds[1]
+        f.parent, f.levels_up = -1, 0
+        self._prims = (PtxPrim * max(len(prims), 1))()
+        for q, d in zip(self._prims, prims):
+            q.kind, q.material, q.frame, q.levels_in = d["kind"], d.get("material", 0), 0, d.get("levels_in", 1)
+            pp = np.zeros(9, np.float32)
+            pp[: len(d["p"])] = d["p"]
+            q.p[:] = pp
+            q.normal[:] = d.get("normal", (0, 0, 0))
+            q.world[:] = d.get("world", ident)
+            q.world_inv[:] = d.get("world_inv", ident)
+        mats = materials or [dict()]
+        self._mats = (PtxMaterial * len(mats))()
+        for m, d in zip(self._mats, mats):
+            m.ka[:] = d.get("ka", (0.2, 0.2, 0.2))
+            m.kd[:] = d.get("kd", (0.5, 0.5, 0.5))
+            m.ks[:] = d.get("ks", (0, 0, 0))
+            m.m, m.glossy, m.opacity, m.ior = d.get("m", 0), d.get("glossy", 0), d.get("opacity", 1), d.get("ior", 1)
+        self._lights = (PtxLight * max(len(lights), 1))()
+        for l, (pos, inten) in zip(self._lights, lights):
+            l.position[:] = pos
+            l.intensity[:] = inten
+        cam = PtxCamera(60.0, (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(0, 0, -1), (C.c_float * 3)(0, 1, 0)) if camera is None else camera
+        self._desc = PtxSceneDesc(self._frames, 1, self._prims, len(prims), self._mats, len(mats), self._lights, len(lights),
+                                  (C.c_float * 3)(*ambient), cam)
+        self.desc = C.pointer(self._desc)
 
 
 def _check(status):

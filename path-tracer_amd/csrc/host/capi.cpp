@@ -51,6 +51,23 @@ void pth_tree_stats(void* h, int* composites, int* leaf_entries, int* max_depth)
 	*max_depth = f.max_tree_depth;
 }
 
+// World matrix and inverse (16 floats each, column-major) of a Shape that got the transforms
+// `xf` in order, through the mirror's Shape::translate / rotate / scale (framework/shape.cpp:17-36):
+// n_xf ops of 4 floats {op, a, b, c}, op 1 = translate(a, b, c), 2 = rotate(yaw a, pitch b, roll c;
+// radians, the unit of Shape::rotate), 3 = scale(a, b, c).  For callers that describe single shapes
+// themselves (PtxPrim::world / world_inv) instead of loading a scene file.
+void pth_shape_matrices(const float* xf, int n_xf, float* world16, float* world_inv16) {
+	Sphere sh;
+	for (int k = 0; k < n_xf; ++k) {
+		const float* q = xf + 4 * k;
+		if (q[0] == 1) sh.translate(q[1], q[2], q[3]);
+		else if (q[0] == 2) sh.rotate(q[1], q[2], q[3]);
+		else if (q[0] == 3) sh.scale(q[1], q[2], q[3]);
+	}
+	std::memcpy(world16, &sh.world_transform(), 16 * sizeof(float));
+	std::memcpy(world_inv16, &sh.world_transform_inv(), 16 * sizeof(float));
+}
+
 // The drop-in call sequence of source/example.cpp:11-21: Renderer{w,h,file,aa,bounces}.render(scene).
 // color may be NULL.  Returns 0, or -1 with pth_last_error() set.
 int pth_render_file(void* h, unsigned w, unsigned hgt, unsigned aa, unsigned bounces, const char* ppm_path, float* color, double* device_seconds) {

@@ -10,10 +10,12 @@ OUT=$PWD/$1
 mkdir -p $OUT
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "bench ok"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-seconds 0 > $OUT/bench_traced.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --cpu-seconds 0 --no-also > $OUT/bench_traced.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 echo "trace ok"
-PASSES="sq1 sq2 sq4 tcp fetch write" scripts/pmc.sh $1/pmc --steps 1 --warmup 0 --cpu-seconds 0 --no-profile || exit 1
+PASSES="sq1 sq2 sq4 tcp fetch write" scripts/pmc.sh $1/pmc --steps 1 --warmup 0 --cpu-seconds 0 --no-profile --no-also --no-census || exit 1
 python3 scripts/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt
-python3 scripts/pmc_summary.py --traffic $OUT/pmc example.sdf 1920 1080 32 5 96 > $OUT/hbm_traffic.json
+QG=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['config']['queue_gib'])")
+python3 scripts/pmc_summary.py --traffic $OUT/pmc cornell_buster.sdf 1920 1080 32 5 $QG > $OUT/hbm_traffic.json
+python3 scripts/record_table.py $OUT > $OUT/record_table.md
 echo "pmc ok"

@@ -26,14 +26,16 @@ for line in txt.splitlines():
 ns = {}
 for row in csv.DictReader(open(d + '/kernel_stats.csv')):
     nm = row['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-    ns[nm] = float(row['TotalDurationNs']) / images_traced
+    ns[nm] = float(row['AverageNs'])   # per launch; scaled to one image below (the traced run also renders untimed images)
 traffic = json.load(open(d + '/hbm_traffic.json'))
 print('value %.0f Msamples/s, %.1f ms per image, roofline %s' % (bench['value'], bench['ms_per_step'], json.dumps(bench['roofline'])))
 print('| kernel | ms | HBM traffic | vector ALU busy | lanes active in VALU instr. | waves parked (SQ_WAIT_ANY) | L1 hit | fp32 FMA+MUL |')
 tot_t = tot_b = 0
-for k in ('k_trace<true, false>', 'k_trace<false, false>', 'k_shade<true, true>', 'k_shade<false, true>', 'k_shadow<false>'):
+names = sorted((k for k in ns if k.startswith(('k_trace', 'k_shade', 'k_shadow', 'k_bounce')) and 'TestCount' not in k and k in data and k in traffic),
+               key=lambda k: -ns[k] * traffic[k]['launches'])
+for k in names:
     c = data[k]
-    t = ns[k] * 1e-9
+    t = ns[k] * 1e-9 * traffic[k]['launches']   # launches per image = dispatches of the one-image counter passes
     simd_cycles = t * 2.4e9 * 1024
     gb = traffic[k]['hbm_bytes_per_launch'] * traffic[k]['launches'] / 1e9
     tot_t += t

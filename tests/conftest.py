@@ -5,6 +5,12 @@ import sys
 import numpy as np
 import pytest
 
+# torch first: its wheel carries its own HIP runtime (same soname as the system's), and a
+# process that loads libptx.so before torch ends up with two runtimes side by side; loaded in
+# this order libptx.so binds to the runtime torch brought, and the tensors the tests hand to the
+# library belong to the runtime that launches the kernels.
+import torch  # noqa: F401,E402
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "oracle"))

@@ -1,0 +1,232 @@
+"""Device parity for single shapes and for transformed shapes at the root, through the C ABI.
+
+* the reference's own answers for six primitives (tests/golden/primitives.npz: Sphere / Box /
+  Triangle::intersect of the real reference on 1 500 rays each, three of them translated,
+  rotated and scaled) replayed on the device as one-shape scenes;
+* a root with rotated, scaled and rotated+scaled boxes and spheres, rays from outside and from
+  inside the shapes, against the CPU oracle;
+* BASELINE configs[2] (cornell + buster_sword mesh, 1920x1080, 1024 spp) at its full size through
+  size-independent properties;
+* a closed room of mirrors around a mesh with the smallest queue memory: nothing overflows.
+
+Bars as in test_gpu_parity.py: hit identity exact, t / position / normal / ray_direction
+bit-identical, images RMSE <= 1e-6 and max abs <= 1e-5 on the tone-mapped floats.
+"""
+import numpy as np
+import pytest
+
+from conftest import beq, load_golden
+from test_gpu_parity import PIPELINES, assert_image_close
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def glm_normalize(v):
+    """v * (1 / sqrt(dot(v, v))) in fp32 with GLM's evaluation order (func_geometric.inl:252-261),
+    which is what the root Composite applies once more to a leaf's normal (composite.cpp:100)"""
+    v = np.asarray(v, f32)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    dot = (x * x + y * y).astype(f32) + (z * z).astype(f32)
+    inv = (f32(1.0) / np.sqrt(dot.astype(f32))).astype(f32)
+    return (v * inv[:, None]).astype(f32)
+
+
+def test_reference_primitive_answers_on_device(pt):
+    """Every case of primitives.npz as a one-shape scene: the shape under an untransformed root
+    whose bounds contain everything (so that only the shape's own intersect decides), matrices
+    from the host mirror's Shape::translate / rotate / scale.  hit / t / position / ray_direction
+    must equal the reference's HitPoint bit for bit; the normal equals the reference's after the
+    one normalize() the root Composite adds (composite.cpp:100)."""
+    g = load_golden("primitives")
+    o, d = g["rays_o"], g["rays_d"]
+    tested = 0
+    for i in range(int(g["n_prims"])):
+        kind, p, xf = int(g[f"kind{i}"]), g[f"p{i}"], g[f"xf{i}"]
+        w, wi = pt.shape_matrices(xf)
+        prim = dict(kind=kind, p=p, world=w, world_inv=wi)
+        if kind == 2:   # Triangle's n_ = normalize(cross(v1 - v0, v2 - v0)), framework/triangle.cpp:11
+            e1, e2 = (p[3:6] - p[0:3]).astype(f32), (p[6:9] - p[0:3]).astype(f32)
+            c = np.array([e1[1] * e2[2] - e2[1] * e1[2], e1[2] * e2[0] - e2[2] * e1[0], e1[0] * e2[1] - e2[0] * e1[1]], f32)
+            prim["normal"] = glm_normalize(c[None])[0]
+        ds = pt.DeviceScene(pt.DescScene([prim]), 0, 1 << 26)
+        a = ds.intersect(o, d)
+        hit = g[f"hit{i}"]
+        assert np.array_equal(a["hit"], hit), i
+        assert hit.sum() > 20
+        for k in ("t", "pos", "raydir"):
+            assert beq(a[k][hit], g[f"{k}{i}"][hit]), (i, k)
+        assert beq(a["normal"][hit], glm_normalize(g[f"normal{i}"][hit])), i
+        tested += int(hit.sum())
+        ds.close()
+    assert tested > 400
+    # the hand-checkable sphere cases (hit / miss / tangent) with the reference's values
+    ds = pt.DeviceScene(pt.DescScene([dict(kind=0, p=[0, 0, 0, 2])]), 0, 1 << 26)
+    a = ds.intersect(g["kat_o"], g["kat_d"])
+    assert np.array_equal(a["hit"], g["kat_hit"]) and beq(a["t"][g["kat_hit"]], g["kat_t"][g["kat_hit"]])
+
+
+def transformed_root_scene(tmp_path):
+    rng = np.random.default_rng(17)
+    lines = ["define material a 1 0 0 1 0 0 1 1 1 20 0 1 1", "define material b 0 1 0 0 1 0 1 1 1 8 0.4 1 1.3",
+             "define material c 0 0 1 0 0 1 1 1 1 50 0.1 0.3 1.5", "define material d .8 .8 .8 .8 .8 .8 0 0 0 0 0 1 1"]
+    tf, names = [], []
+    for k in range(40):     # <= 64 shapes under the root: the reference keeps them in one list
+        x, y, z = rng.uniform(-6, 6), rng.uniform(-3, 3), rng.uniform(-20, -6)
+        m = "abcd"[k % 4]
+        if k % 2 == 0:
+            e = rng.uniform(0.8, 2.5, 3)
+            name = f"b{k:02d}"
+            lines.append(f"define shape box {name} {-e[0] / 2:.3f} {-e[1] / 2:.3f} {-e[2] / 2:.3f} {e[0] / 2:.3f} {e[1] / 2:.3f} {e[2] / 2:.3f} {m}")
+        else:
+            name = f"s{k:02d}"
+            lines.append(f"define shape sphere {name} 0 0 0 {rng.uniform(0.5, 1.5):.3f} {m}")
+        names.append(name)
+        tf.append(f"transform {name} translate {x:.3f} {y:.3f} {z:.3f}")
+        mode = k % 8 // 2       # 0 rotate, 1 scale, 2 rotate + scale, 3 scale + rotate
+        rot = f"transform {name} rotate {rng.uniform(-180, 180):.1f} {rng.uniform(-90, 90):.1f} {rng.uniform(-180, 180):.1f}"
+        scl = f"transform {name} scale {rng.uniform(0.4, 2.0):.2f} {rng.uniform(0.4, 2.0):.2f} {rng.uniform(0.4, 2.0):.2f}"
+        tf += {0: [rot], 1: [scl], 2: [rot, scl], 3: [scl, rot]}[mode]
+    lines += ["define shape box room -9 -5 -24 9 5 2 d", "define light sun 0 4.5 -8 .8 .8 .8 1", "define light fill -6 2 0 .2 .2 .3 1",
+              "define ambient amb 1 1 1 0.2", "define camera eye 60 0 0 1 0 0 0"] + tf
+    sdf = tmp_path / "turned.sdf"
+    sdf.write_text("\n".join(lines) + "\n")
+    return str(sdf)
+
+
+def test_rotated_and_scaled_root_shapes(pt, port, tmp_path):
+    """Rotated, scaled, rotated+scaled and scaled+rotated boxes and spheres directly under the root
+    (the branch of the root-leaf test that carries the ray through the shape's full inverse matrix,
+    and the box / sphere branches of the surface rebuild under a rotation), inside one big box so
+    that every ray ends somewhere.  Rays: primary rays, random rays from outside, and rays that
+    start INSIDE each shape (the far root of a sphere, t_max of a box)."""
+    from oracle_lib import random_rays
+    sdf = transformed_root_scene(tmp_path)
+    hs = pt.HostScene(sdf)
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    assert ds.info()["n_bvh_nodes"] > 0 or hs.n_prims <= 16
+    s = port.load(sdf)
+    o1, d1 = port.primary_rays(s, 240, 160, 1)
+    o2, d2 = random_rays(40000, 3, lo=(-8, -4, -22), hi=(8, 4, 1))
+    # rays from inside the shapes: origins at the world-space centres (the translation of each transform)
+    centres = []
+    for line in open(sdf):
+        q = line.split()
+        if len(q) == 6 and q[0] == "transform" and q[2] == "translate":
+            centres.append([float(v) for v in q[3:6]])
+    centres = np.array(centres, f32)
+    assert len(centres) == 40
+    _, d3 = random_rays(40 * 200, 4)
+    o3 = np.repeat(centres, 200, axis=0)
+    o, d = np.concatenate([o1, o2, o3]), np.concatenate([d1, d2, d3])
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    assert m.sum() > 0.9 * len(o)
+    names = hs.prim_names()
+    inside = a["prim"][len(o1) + len(o2):]
+    own = sum(names[p] == "bs"[k // 200 % 2] + f"{k // 200:02d}" for k, p in enumerate(inside) if p >= 0)
+    assert own > 0.6 * len(inside)          # most rays from a shape's centre hit that shape from the inside (the shapes overlap a little)
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    hit_kinds = {names[p][0] for p in np.unique(a["prim"][m])}
+    assert hit_kinds >= {"b", "s", "r"}
+    ref = port.render(s, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    # the list variant of the closest-hit kernels (at most 16 root leaves) on a subset of the same shapes
+    few = [l for l in open(sdf) if not any(f" {n} " in l or l.rstrip().endswith(" " + n) for n in [f"b{k:02d}" for k in range(12, 40, 2)] + [f"s{k:02d}" for k in range(13, 40, 2)])]
+    sdf2 = tmp_path / "turned_few.sdf"
+    sdf2.write_text("".join(few))
+    hs2 = pt.HostScene(str(sdf2))
+    assert hs2.n_prims == 13
+    ds2, s2 = pt.DeviceScene(hs2, 0, 1 << 28), port.load(str(sdf2))
+    assert ds2.info()["n_bvh_nodes"] == 0
+    a, b = ds2.intersect(o, d), port.intersect(s2, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    ref = port.render(s2, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds2.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+
+
+def test_full_size_properties_mesh(pt, scenes):
+    """BASELINE configs[2] at its full size (cornell + buster_sword, 16 008 triangles, 1920x1080,
+    1024 spp, 5 bounces: 2.1 G samples, 9 G rays; the CPU oracle would need hours).  The staged
+    pipeline with the library's default queue memory (13 chunks of primary samples per image, the
+    parked mesh walks under full load), the staged pipeline in 2 GiB (hundreds of chunks) and the
+    fused pipeline agree to the image bar and count exactly the same rays, shadow rays and hits
+    at every depth; the image is the sum of eight ranks' sample ranges."""
+    import importlib
+    import torch
+    hs = scenes.host_scene("cornell_buster")
+    w, h, aa, nb = 1920, 1080, 32, 5
+    ds = pt.DeviceScene(hs, 0, 0)
+    a = ds.render_image(w, h, aa, nb, pipeline="staged")
+    b = ds.render_image(w, h, aa, nb, pipeline="fused")
+    assert_image_close(a["color"], b["color"], a["rgb"], b["rgb"])
+    sa, sb = a["stats"], b["stats"]
+    assert sa["samples"] == w * h * aa * aa == sa["per_depth_rays"][0]
+    for k in ("trace_rays", "shadow_rays", "shaded_hits"):
+        assert sa[k] == sb[k], k
+    for k in ("per_depth_rays", "per_depth_shadow", "per_depth_hits"):
+        assert sa[k][:nb + 1] == sb[k][:nb + 1], k
+    assert sa["per_depth_hits"][0] == sa["samples"]      # a closed room: every primary ray hits something
+    dist = importlib.import_module("path-tracer_amd.dist")
+    acc = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(8):
+        s0, s1 = dist.sample_range(rank, 8, aa * aa)
+        ds.render_accumulate(pt.render_params(w, h, aa, nb, s0, s1), acc.data_ptr(), stream, check_overflow=True)
+    color = torch.empty(h * w * 3, dtype=torch.float32, device="cuda:0")
+    rgb = torch.empty(h * w * 3, dtype=torch.uint8, device="cuda:0")
+    ds.resolve(acc.data_ptr(), w, h, aa * aa, color.data_ptr(), rgb.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert_image_close(color.cpu().numpy().reshape(h, w, 3), a["color"], rgb.cpu().numpy().reshape(h, w, 3), a["rgb"])
+    assert np.isfinite(a["color"]).all() and (a["color"] >= 0).all()
+    ds.close()
+    small = pt.DeviceScene(hs, 0, 2 << 30)
+    c = small.render_image(w, h, aa, nb, pipeline="staged")
+    assert_image_close(c["color"], a["color"], c["rgb"], a["rgb"])
+    for k in ("trace_rays", "shadow_rays", "shaded_hits"):
+        assert c["stats"][k] == sa[k], k
+    assert c["stats"]["launches"] > 4 * sa["launches"]
+    small.close()
+
+
+def test_mirror_room_around_a_mesh_in_small_queues(pt, port, tmp_path):
+    """A closed room whose six walls are mirrors, a mesh inside it, deep ray trees, the smallest
+    queue memory: every ray hits something at every depth, and the rays that reach the mesh are
+    parked and walked later by the closest-hit kernel, i.e. the hit list of a launch receives more
+    batches of records than the launch has steps.  Nothing may overflow (the call checks), both
+    pipelines give the reference's image and count the same rays."""
+    import shutil
+    shutil.copy(pt.SDF_DIR + "/sword.obj", tmp_path / "sword.obj")
+    shutil.copy(pt.SDF_DIR + "/sword.mtl", tmp_path / "sword.mtl")
+    sdf = tmp_path / "mirror_room.sdf"
+    sdf.write_text("define material mirror 0.1 0.1 0.1 0.2 0.2 0.2 0.9 0.9 0.9 20 1 1 1\n"
+                   "define shape box left -4 -3 -12 -3.5 3 4 mirror\ndefine shape box right 3.5 -3 -12 4 3 4 mirror\n"
+                   "define shape box back -4 -3 -12.5 4 3 -12 mirror\ndefine shape box front -4 -3 4 4 3 4.5 mirror\n"
+                   "define shape box floor -4 -3.5 -12.5 4 -3 4.5 mirror\ndefine shape box ceil -4 3 -12.5 4 3.5 4.5 mirror\n"
+                   "define shape obj sword\n"
+                   "define light l 0 2.5 -2 .8 .8 .8 1\ndefine ambient amb 1 1 1 0.1\ndefine camera eye 70 0 0 3 10 0 0\n"
+                   "transform sword translate 0 -1 -6\ntransform sword rotate 30 20 0\ntransform sword scale 2 2 2\n")
+    hs = pt.HostScene(str(sdf), str(tmp_path) + "/")
+    s = port.load(str(sdf), str(tmp_path) + "/")
+    small = pt.DeviceScene(hs, 0, 1)
+    big = pt.DeviceScene(hs, 0, 1 << 30)
+    w, h, aa, nb = 64, 40, 2, 24
+    ref = port.render(s, w, h, aa, nb, counters=True)
+    stats = []
+    for ds in (small, big):
+        for pipeline in PIPELINES:
+            r = ds.render_image(w, h, aa, nb, pipeline=pipeline)     # (render_image checks the overflow flag)
+            assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+            st = r["stats"]
+            assert st["per_depth_hits"][:10] == st["per_depth_rays"][:10]      # a closed room: every ray hits
+            stats.append((st["trace_rays"], st["shadow_rays"], st["shaded_hits"]))
+    assert len(set(stats)) == 1 and stats[0][0] > 10 * w * h * aa * aa
