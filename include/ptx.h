@@ -214,6 +214,28 @@ PtxStatus ptx_render_accumulate(PtxScene* scene, const PtxRenderParams* params, 
                                 int check_overflow, PtxStats* stats);
 
 /*
+ * ptx_render_accumulate for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same kernels, same results; the queues and counters live in a
+ * 128 MiB array inside the library's code object (every GPU that runs the library holds its own
+ * copy until the process ends; ptx_scene_create looks its address up once per device) instead of
+ * the scene's own block, and the call allocates and frees nothing: no hipMalloc / hipFree, no
+ * event creation (profiling set with ptx_scene_set_profiling is ignored here: the kernel_ms fields
+ * of `stats` stay zero).
+ * Limits: at most PTX_STATIC_MAX_SAMPLES samples (width * height * (sample_end - sample_begin))
+ * and max_ray_bounces <= PTX_STATIC_MAX_BOUNCES per call, else PTX_ERR_INVALID; PTX_ERR_NOMEM if
+ * the scene's lights and bounces still do not fit.  Larger images go through in several calls with
+ * consecutive sample ranges (the sums add up in d_accum).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two threads, two
+ * streams, two scenes) race; run them one after the other.  What must start at zero is cleared
+ * by the call itself.
+ */
+#define PTX_STATIC_MAX_SAMPLES (1u << 24)
+#define PTX_STATIC_MAX_BOUNCES 16u
+PtxStatus ptx_render_accumulate_static(PtxScene* scene, const PtxRenderParams* params, float* d_accum, void* stream,
+                                       int check_overflow, PtxStats* stats);
+
+/*
  * accum / spp -> tone map c/(c+1) (framework/renderer.cpp:86-89, :286-291) -> d_color
  * (w*h*3 floats, the layout of Renderer::color_buffer()) and/or d_rgb8 (w*h*3 bytes, rows
  * flipped and quantised as PpmWriter::write does, framework/ppmwriter.cpp:36-43).

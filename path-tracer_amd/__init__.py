@@ -30,7 +30,7 @@ STATUS_NAMES = {0: "PTX_OK", 1: "PTX_ERR_INVALID", 2: "PTX_ERR_UNSUPPORTED", 3: 
 PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
     "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_write_ppm_binary", "ptx_write_pfm", "ptx_scene_info", "ptx_jitter",
-    "ptx_scene_set_profiling",
+    "ptx_scene_set_profiling", "ptx_render_accumulate_static",
 ]
 
 
@@ -129,6 +129,7 @@ def ptx_lib():
     L.ptx_scene_destroy.argtypes = [vp]
     L.ptx_scene_destroy.restype = None
     L.ptx_render_accumulate.argtypes = [vp, C.POINTER(PtxRenderParams), vp, vp, C.c_int, C.POINTER(PtxStats)]
+    L.ptx_render_accumulate_static.argtypes = L.ptx_render_accumulate.argtypes
     L.ptx_resolve.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.ptx_render_image.argtypes = [vp, C.POINTER(PtxRenderParams), vp, vp, C.POINTER(C.c_double), C.POINTER(PtxStats)]
     L.ptx_intersect.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
@@ -323,9 +324,11 @@ class DeviceScene:
         _check(self.L.ptx_render_image(self.handle, C.byref(rp), _ptr(color), _ptr(rgb), C.byref(sec), C.byref(st)))
         return dict(color=color, rgb=rgb, seconds=sec.value, stats=st.as_dict())
 
-    def render_accumulate(self, rp, d_accum_ptr, stream=None, check_overflow=False, want_stats=False):
+    def render_accumulate(self, rp, d_accum_ptr, stream=None, check_overflow=False, want_stats=False, static=False):
+        """static=True: ptx_render_accumulate_static (work memory inside the library, nothing allocated)"""
         st = PtxStats() if want_stats else None
-        _check(self.L.ptx_render_accumulate(self.handle, C.byref(rp), C.c_void_p(d_accum_ptr), C.c_void_p(stream or 0), int(check_overflow),
+        fn = self.L.ptx_render_accumulate_static if static else self.L.ptx_render_accumulate
+        _check(fn(self.handle, C.byref(rp), C.c_void_p(d_accum_ptr), C.c_void_p(stream or 0), int(check_overflow),
                                             C.byref(st) if st is not None else None))
         return st.as_dict() if st is not None else None
 

@@ -32,6 +32,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -90,6 +91,38 @@ struct WorkMem {
 	Counters* counters = nullptr;  // kCounterBytes
 	unsigned long long* stat = nullptr;  // kStatBytes
 };
+
+// Work memory of ptx_render_accumulate_static, for callers that must not allocate: one array
+// in the code object, of which every GPU that loads the library holds its own copy until the
+// process ends.  In host code the NAME of the array is only a handle (handing it to a kernel
+// compiles and then faults on the device): the array's address on a device comes from
+// hipGetSymbolAddress, asked once per device with that device current (scratch_on) and kept;
+// everything below uses that pointer.  Layout: counters, work counters, segment counts, queues.
+constexpr unsigned kStaticSeg = 2048;  // most segments (waves per grid) of a render in this memory
+constexpr size_t kStaticBytes = 128ull << 20;
+constexpr size_t kStaticStatOff = kCounterBytes;
+constexpr size_t kStaticCountsOff = kStaticStatOff + kStatBytes;
+constexpr size_t kStaticQueueOff = (kStaticCountsOff + count_bytes(kStaticSeg) + 255) & ~(size_t) 255;
+static_assert(kStaticQueueOff + (32ull << 20) <= kStaticBytes, "static work memory: no room left for the queues");
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {};  // the array's address on each device (0 = not asked yet)
+
+// address of `scratch` on `device`, which must be the current device
+static hipError_t scratch_on(int device, unsigned char** out) {
+	std::lock_guard<std::mutex> lock(g_scratch_mutex);
+	if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+	if (!g_scratch_ptr[device]) {
+		void* p = nullptr;
+		hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+		if (e != hipSuccess) return e;
+		g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+	}
+	*out = g_scratch_ptr[device];
+	return hipSuccess;
+}
 
 struct PtxScene {
 	int device = 0;
@@ -237,6 +270,10 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
 		return fail(PTX_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only");
 
+	{  // this device's copy of the static work memory (ptx_render_accumulate_static): its address is asked here, once per device
+		unsigned char* unused = nullptr;
+		HIP_TRY(scratch_on(device, &unused));
+	}
 	std::unique_ptr<PtxScene> sc(new PtxScene);
 	sc->device = device;
 	sc->camera = D->camera;
@@ -562,7 +599,7 @@ namespace {
 // One render into d_accum with the work memory `M` (the scene's own block, or any other that
 // holds the same parts).  Calls no allocating routine unless profiling has to create events.
 PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParams* rp, float* d_accum, hipStream_t stream, int check_overflow,
-                            PtxStats* stats) {
+                            PtxStats* stats, bool may_create_events) {
 	BounceArgs A{};
 	A.S = sc->dev;
 	camera_basis(sc->camera, *rp, A.cam);
@@ -579,7 +616,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	HIP_TRY(hipMemsetAsync(M.counters, 0, kCounterBytes, stream));
 	HIP_TRY(hipMemsetAsync(M.stat, 0, kStatBytes, stream));
 	uint64_t launches = 0;
-	const bool prof = sc->profiling > 0 && stats;
+	const bool prof = sc->profiling > 0 && stats && may_create_events;
 	const bool count_tests = sc->profiling > 1 && stats;
 	const bool staged = rp->pipeline != PTX_PIPELINE_FUSED;  // the default is the staged pipeline (the faster one on the measured scenes)
 	sc->event_tag.clear();
@@ -789,7 +826,36 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	PtxStatus st = check_params(rp);
 	if (st != PTX_OK) return st;
 	HIP_TRY(hipSetDevice(sc->device));
-	return render_accumulate(sc, sc->work, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats);
+	return render_accumulate(sc, sc->work, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats, true);
+}
+
+PtxStatus ptx_render_accumulate_static(PtxScene* sc, const PtxRenderParams* rp, float* d_accum, void* stream_, int check_overflow,
+                                       PtxStats* stats) {
+	if (!sc || !d_accum) return fail(PTX_ERR_INVALID, "scene/d_accum is NULL");
+	PtxStatus st = check_params(rp);
+	if (st != PTX_OK) return st;
+	const uint64_t samples = (uint64_t) rp->width * rp->height * (rp->sample_end - rp->sample_begin);
+	if (samples > PTX_STATIC_MAX_SAMPLES)
+		return fail(PTX_ERR_INVALID, "ptx_render_accumulate_static: " + std::to_string(samples) + " samples in one call, the static work memory takes at most " +
+		                                 std::to_string((uint64_t) PTX_STATIC_MAX_SAMPLES) + " (render a smaller sample range per call, or use ptx_render_accumulate)");
+	if (rp->max_ray_bounces > PTX_STATIC_MAX_BOUNCES)
+		return fail(PTX_ERR_INVALID, "ptx_render_accumulate_static: max_ray_bounces " + std::to_string(rp->max_ray_bounces) + " exceeds the limit of " +
+		                                 std::to_string((unsigned) PTX_STATIC_MAX_BOUNCES) + " of the static work memory");
+	HIP_TRY(hipSetDevice(sc->device));
+	unsigned char* base = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(g_scratch_mutex);
+		base = sc->device < kMaxDevices ? g_scratch_ptr[sc->device] : nullptr;
+	}
+	if (!base) return fail(PTX_ERR_DEVICE, "the static work memory of this device was never set up (ptx_scene_create does that)");
+	WorkMem M;
+	M.counters = reinterpret_cast<Counters*>(base);
+	M.stat = reinterpret_cast<unsigned long long*>(base + kStaticStatOff);
+	M.counts = reinterpret_cast<unsigned*>(base + kStaticCountsOff);
+	M.max_seg = kStaticSeg;
+	M.qmem = reinterpret_cast<float4*>(base + kStaticQueueOff);
+	M.qslots = ((kStaticBytes - kStaticQueueOff) / 48) & ~127ull;
+	return render_accumulate(sc, M, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats, false);
 }
 
 PtxStatus ptx_resolve(int device, const float* d_accum, uint32_t w, uint32_t h, uint32_t spp, float* d_color, uint8_t* d_rgb8,
