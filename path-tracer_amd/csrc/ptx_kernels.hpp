@@ -325,12 +325,14 @@ __device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 o, f3 d) {
 // arithmetic.  16 instructions against 45 to 100 for an exact test, and a wave whose 64 rays
 // all fail (the usual case for the rays of one pixel: of the six walls of a room they see
 // one) skips the leaf altogether.  NaN compares false and so passes.
-__device__ __forceinline__ bool may_hit_box(float4 lo, float4 hi, const RayPre& pre) {
+// `limit`: a leaf the ray enters beyond it cannot matter (cull_limit of the best distance so far, or
+// of a shadow ray's range; the ray parameter is the same in every space, so one limit serves all leaves).
+__device__ __forceinline__ bool may_hit_box(float4 lo, float4 hi, const RayPre& pre, float limit) {
 	float ax = __builtin_fmaf(lo.x, pre.finv.x, pre.fnoi.x), bx = __builtin_fmaf(hi.x, pre.finv.x, pre.fnoi.x);
 	float ay = __builtin_fmaf(lo.y, pre.finv.y, pre.fnoi.y), by = __builtin_fmaf(hi.y, pre.finv.y, pre.fnoi.y);
 	float az = __builtin_fmaf(lo.z, pre.finv.z, pre.fnoi.z), bz = __builtin_fmaf(hi.z, pre.finv.z, pre.fnoi.z);
 	float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-	float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+	float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limit));
 	return !(tn > tf);
 }
 
@@ -489,7 +491,7 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	}
 	for (int i = 0; i < S.n_root_prims; ++i) {
 		tc.slab();
-		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
+		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, cull_limit(best.t)))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
 		float t;
 		const bool hit = root_prim_t(S, P, o, d, pre, t, tc);
@@ -550,9 +552,10 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 	if (RB && S.root_bvh) {
 		if (root_walk<true>(S, o, d, pre, stk, dummy, range, tc)) return true;
 	} else {
+		const float limit = cull_limit(range);
 		for (int i = 0; i < S.n_root_prims; ++i) {
 			tc.slab();
-			if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre))) continue;
+			if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, limit))) continue;
 			const DevRootPrim P = kload(S.root_prims_k + i);
 			if (root_prim_t(S, P, o, d, pre, t, tc) && t <= range) return true;
 		}
@@ -903,6 +906,17 @@ struct BounceArgs {
 	unsigned* hit_count;
 };
 
+// Software pipelining of the queue kernels.  The memory counter of a wave (vmcnt) retires loads,
+// stores and atomics strictly in issue order, and the compiler, which cannot count the stores of
+// divergent branches, waits for ALL of them (vmcnt(0)) wherever a loaded value is first used.  A
+// step that stores or adds its results at its end and then loads the next step's records
+// therefore stands still for a full trip to memory (atomics: several microseconds under load)
+// once or twice per step.  So every step issues ALL its memory traffic in one burst at its TOP -
+// the stores / atomics of the step before (kept in registers or LDS until then) and the loads
+// of the step after - and then computes; by the next top everything has long arrived, and the one
+// wait there (pipeline_wait) is free.
+__device__ __forceinline__ void pipeline_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // s_waitcnt vmcnt(0)
+
 // this wave's number: the same in every lane, and known to the compiler to be (scalar registers, scalar loads)
 __device__ __forceinline__ unsigned wave_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)); }
 
@@ -1116,6 +1130,23 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		parked -= count;
 		emit(h.id >= 0, h, ref);
 	};
+	// depth > 0: planes a, b of the ray records (origin, direction; the weight and the pixel are
+	// the shading kernel's business), fetched one step ahead; the hit records of a step are stored
+	// at the top of the next one (see pipeline_wait)
+	// (a lane without a record reads its segment's first slot instead: an unconditional load goes
+	// straight into the registers the next step reads, a conditional one would be copied there
+	// behind a wait)
+	float4 next_a = make_float4(0.f, 0.f, 0.f, 0.f), next_b = next_a;
+	auto fetch = [&](unsigned k) {
+		unsigned ref;
+		if (!step_record<PRIMARY>(A, wave, n, k, lane, ref)) ref = wave * A.seg_cap;
+		next_a = A.in.a[ref];
+		next_b = A.in.b[ref];
+	};
+	float4 pend_rec = make_float4(0.f, 0.f, 0.f, 0.f);
+	unsigned pend_at = 0;
+	bool pend = false;
+	if (!PRIMARY && steps) fetch(0);
 	for (unsigned k = 0; k < steps; ++k) {
 		unsigned ref;
 		const bool active = step_record<PRIMARY>(A, wave, n, k, lane, ref);
@@ -1126,10 +1157,21 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		h.t = kInf;
 		f3 o = {0, 0, 0}, d = {0, 0, 1}, w;
 		unsigned pix, frames = 0;
+		if (!PRIMARY) {
+			pipeline_wait();
+			const float4 a = next_a, b = next_b;
+			if (pend) my_hits[pend_at] = pend_rec;
+			pend = false;
+			fetch(k + 1 < steps ? k + 1 : k);
+			if (active) {
+				o = mk(a.x, a.y, a.z);
+				d = mk(a.w, b.x, b.y);
+			}
+		} else if (active) {
+			input_ray<PRIMARY>(A, ref, o, d, w, pix);
+		}
 		RayPre pre = ray_pre(A.S, o, d);
 		if (active) {
-			input_ray<PRIMARY>(A, ref, o, d, w, pix);
-			pre = ray_pre(A.S, o, d);
 			if (closest_root<RB>(A.S, o, d, pre, stk, h, tc)) frames = frame_mask(A.S, o, d, pre, tc);
 			++cnt_trace;
 		}
@@ -1143,7 +1185,16 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h, tc);
 			park = false;
 		}
-		emit(h.id >= 0 && !park, h, ref);
+		if (PRIMARY) {
+			emit(h.id >= 0 && !park, h, ref);
+		} else {  // the step's own hits: placed now, stored at the top of the next step
+			const bool hit = h.id >= 0 && !park;
+			const unsigned long long hm = __ballot(hit);
+			pend = hit;
+			pend_at = n_hit + __builtin_popcountll(hm & lanes_below(lane));
+			pend_rec = make_float4(h.t, __int_as_float(h.id), __int_as_float(h.frame == 0 ? h.slot : -h.frame), __uint_as_float(ref));
+			n_hit += __builtin_popcountll(hm);
+		}
 		if (np && !walk_now) {
 			if (parked + np > kRing) walk_parked(parked < 64 ? parked : 64);
 			if (park) {
@@ -1157,6 +1208,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			if (parked >= 64) walk_parked(64);
 		}
 	}
+	if (pend) my_hits[pend_at] = pend_rec;
 	if (parked) walk_parked(parked);
 	if (lane == 0) A.hit_count[wave] = n_hit;
 	unsigned long long* st = stat_slot(A, wave);
@@ -1252,7 +1304,10 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 // find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
 // unblocked ray adds its contribution to its pixel
 template <bool RB, class TC>
-__global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
+#ifndef PTX_SHADOW_WAVES
+#define PTX_SHADOW_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
@@ -1261,27 +1316,51 @@ __global__ __launch_bounds__(kBlock, 5) void k_shadow(BounceArgs A) {
 	const unsigned steps = (n + 63) >> 6;
 	const size_t seg_base = (size_t) wave * A.seg_cap;
 	TC tc;
-	for (unsigned k = 0; k < steps; ++k) {
+	// records one step ahead, sums one step behind (see pipeline_wait)
+	// (a lane without a record reads the segment's first slot: see k_trace)
+	float4 next_a = make_float4(0.f, 0.f, 0.f, 0.f), next_b = next_a;
+	auto fetch = [&](unsigned k) {
 		const unsigned r = k * 64 + lane;
-		const bool active = r < n;
+		const size_t j = seg_base + (r < n ? r : 0u);
+		next_a = A.shadow.a[j];
+		next_b = A.shadow.b[j];
+	};
+	if (steps) fetch(0);
+	unsigned prev_pix = 0;
+	f3 prev_c = {0, 0, 0};
+	bool prev_lit = false;
+	for (unsigned k = 0; k < steps; ++k) {
+		pipeline_wait();
+		const float4 a = next_a, b = next_b;
+		accumulate(A.accum, prev_pix, prev_c, prev_lit);
+		fetch(k + 1 < steps ? k + 1 : k);
+		const bool active = k * 64 + lane < n;
+		// the light's position through scalar loads, light by light (a vector load here would make
+		// the wave wait for the records just requested)
+		const int light = __float_as_int(b.w);
+		f3 lpos = {0, 0, 0};
+		for (int l = 0; l < A.S.n_lights; ++l) {
+			const float4 lp = kload(A.S.lights_k + 2 * l);
+			if (light == l) lpos = mk(lp.x, lp.y, lp.z);
+		}
 		unsigned pix = 0;
 		f3 c = {0, 0, 0};
 		bool lit = false;
 		if (active) {
-			const size_t j = seg_base + r;
-			const float4 a = A.shadow.a[j], b = A.shadow.b[j];
 			pix = __float_as_uint(a.w);
 			c = mk(b.x, b.y, b.z);
 			// direction and distance to the light exactly as light_term formed them (renderer.cpp:144-147)
-			const float4 lp = A.S.lights[2 * __float_as_int(b.w)];
 			const f3 pos = mk(a.x, a.y, a.z);
-			f3 ldir = mk(lp.x, lp.y, lp.z) - pos;
+			f3 ldir = lpos - pos;
 			const float dist = length(ldir);
 			ldir = normalize(ldir);
 			lit = !trace_any<RB>(A.S, pos, ldir, dist, stk, tc);
 		}
-		accumulate(A.accum, pix, c, lit);
+		prev_pix = pix;
+		prev_c = c;
+		prev_lit = lit;
 	}
+	accumulate(A.accum, prev_pix, prev_c, prev_lit);
 	stat_add_tests(stat_slot(A, wave), 3 + kTestKinds, tc);
 }
 
