@@ -34,6 +34,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ptx.h"
@@ -505,6 +506,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		for (int i = 0; i < D->n_prims; ++i) std::memcpy(&prim_mats[(size_t) i * 4], &mats[(size_t) D->prims[i].material * 4], 4 * sizeof(float4));
 		if ((st = sc->upload(prim_mats, &S.materials)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	}
+	if ((st = sc->upload(mats, &S.mat_table)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(lights, &S.lights)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	// same addresses; copied as bits because the device pass types the *_k members differently
 	std::memcpy(&S.root_prims_k, &S.root_prims, sizeof(void*));
@@ -516,6 +518,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	S.n_frames = D->n_frames;
 	S.n_lights = D->n_lights;
 	S.n_prims = D->n_prims;
+	S.n_materials = D->n_materials;
 	std::memcpy(S.ambient, D->ambient, sizeof S.ambient);
 	std::memcpy(S.root_min, D->frames[0].bounds_min, sizeof S.root_min);
 	std::memcpy(S.root_max, D->frames[0].bounds_max, sizeof S.root_max);
@@ -700,8 +703,16 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		}
 		HIP_TRY(tick(0, d, false));
 		HIP_TRY(tick(1, d, true));
-		auto kern = d == 0 ? (ip ? k_shade<true, true> : k_shade<true, false>) : (ip ? k_shade<false, true> : k_shade<false, false>);
-		hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
+		{
+			// the small tables of the scene from LDS copies when they fit
+			const bool lt = A.S.n_root_prims <= kLdsRoot && A.S.n_frames <= kLdsFrames && A.S.n_materials <= kLdsMats;
+			auto pick = [&](auto primary) {
+				constexpr bool P = decltype(primary)::value;
+				return ip ? (lt ? k_shade<P, true, true> : k_shade<P, true, false>) : (lt ? k_shade<P, false, true> : k_shade<P, false, false>);
+			};
+			auto kern = d == 0 ? pick(std::true_type{}) : pick(std::false_type{});
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
+		}
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));

@@ -83,6 +83,7 @@ struct DevScene {
 	const float4* prim_info;  // per prim id: the normal a hit on a triangle reports, finished at upload (w: bits(material | levels_in << 16))
 	const float4* materials;  // 4 float4 per PRIM id (its material, so that a hit needs no second, dependent fetch):
 	                          // (ka, kd.x) (kd.yz, ks.xy) (ks.z, m, glossy, opacity) (ior,-,-,-)
+	const float4* mat_table;  // the same 4 float4 per MATERIAL id (the shading kernel keeps a copy in LDS)
 	const float4* lights;     // 2 float4 per light: (pos, -) (intensity, -)
 	// the same tables once more, for the wave-uniform reads (kload)
 	PTX_KPTR(DevRootPrim) root_prims_k;
@@ -91,7 +92,7 @@ struct DevScene {
 	PTX_KPTR(Mat16) frame_winv_k;
 	PTX_KPTR(float4) lights_k;
 	PTX_KPTR(float4) root_bound_k;  // per frame-0 leaf: padded bounding box in frame-0 space, 2 x float4 (lo, hi)
-	int32_t n_root_prims, n_frames, n_lights, n_prims;
+	int32_t n_root_prims, n_frames, n_lights, n_prims, n_materials;
 	int32_t has_plain_sphere;
 	int32_t root_bvh;        // != 0: the leaves of frame 0 are many and sit under a BVH of their own (root_walk)
 	int32_t root_bvh_root;   // its root reference
@@ -581,17 +582,30 @@ struct Surface {  // the HitPoint fields shading reads, framework/hitPoint.hpp:8
 	f3 pos, n, rdir;
 };
 
+// Where shading reads the small per-leaf / per-mesh / per-material tables from: the device
+// tables, or copies of them in LDS (k_shade).
+struct ShadeTables {
+	const DevRootPrim* prim;    // per frame-0 leaf
+	const DevRootShade* shade;  // per frame-0 leaf
+	const DevXform* xf;         // per frame-0 leaf
+	const Mat16* fwinv;         // per frame
+	const Mat16* fw;            // per frame
+	const float4* mats;         // 4 float4 per material id
+};
+__device__ __forceinline__ ShadeTables device_tables(const DevScene& S) { return {S.root_prims, S.root_shade, S.xforms, S.frame_winv, S.frame_w, S.mat_table}; }
+
 // Rebuilds position / normal / ray_direction of the winning leaf exactly as the leaf and
-// the Composites above it would have produced them.
-__device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
+// the Composites above it would have produced them.  `info` = prim_info of the hit prim (read
+// for mesh triangles only).
+__device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, const Hit& h, float4 info) {
 	Surface s;
 	if (h.frame == 0) {
-		const DevRootPrim& P = S.root_prims[h.slot];
-		const DevRootShade& Q = S.root_shade[h.slot];
+		const DevRootPrim& P = T.prim[h.slot];
+		const DevRootShade& Q = T.shade[h.slot];
 		const int kind = P.kind_flags & 0xff;
 		// the shape's real matrices, also for translated-only shapes: the zeros of an inverted
 		// translation carry signs, and the sign of a zero normal component follows them
-		const DevXform& X = S.xforms[h.slot];  // one per root leaf, in the same order
+		const DevXform& X = T.xf[h.slot];  // one per root leaf, in the same order
 		f3 lo = xform_point(X.winv, o), ld = xform_dir(X.winv, d);
 		if (kind == PTX_TRIANGLE) {  // framework/triangle.cpp:86
 			s.pos = o + d * h.t;
@@ -610,25 +624,38 @@ __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, con
 			for (int k = 0; k < Q.levels_in; ++k) s.n = normalize(s.n);  // identity-transform Composites up to the root
 		}
 	} else {
-		const float* Fwinv = S.frame_winv[h.frame].m;  // h.frame differs between lanes: ordinary loads
-		const float* Fw = S.frame_w[h.frame].m;
+		const float* Fwinv = T.fwinv[h.frame].m;  // h.frame differs between lanes: per-lane reads
+		const float* Fw = T.fw[h.frame].m;
 		f3 lo = xform_point(Fwinv, o), ld = xform_dir(Fwinv, d);
-		float4 info = S.prim_info[h.id];
 		s.n = mk(info.x, info.y, info.z);  // constant per triangle: the whole chain of Composites applied at upload
 		s.pos = xform_point(Fw, lo + ld * h.t);
 		s.rdir = ld;  // stays in mesh-local space: Composite never maps ray_direction back
 	}
 	return s;
 }
+__device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
+	float4 info = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (h.frame != 0) info = S.prim_info[h.id];
+	return surface_of(device_tables(S), o, d, h, info);
+}
 
 struct Material {
 	f3 ka, kd, ks;
 	float m, glossy, opacity, ior;
 };
+__device__ __forceinline__ Material unpack_material(float4 a, float4 b, float4 c, float4 e) {
+	return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, c.y, c.z, c.w, e.x};
+}
 __device__ __forceinline__ Material load_material(const DevScene& S, int prim_id) {
 	const float4* p = S.materials + (size_t) prim_id * 4;
-	float4 a = p[0], b = p[1], c = p[2], e = p[3];
-	return {{a.x, a.y, a.z}, {a.w, b.x, b.y}, {b.z, b.w, c.x}, c.y, c.z, c.w, e.x};
+	return unpack_material(p[0], p[1], p[2], p[3]);
+}
+// the material of a hit through the table by material id: a frame-0 leaf names its material in
+// its shading record, a mesh triangle in the low half of prim_info.w
+__device__ __forceinline__ Material material_of(const ShadeTables& T, const Hit& h, float4 info) {
+	const int mid = h.frame == 0 ? T.shade[h.slot].material : (__float_as_int(info.w) & 0xffff);
+	const float4* p = T.mats + (size_t) mid * 4;
+	return unpack_material(p[0], p[1], p[2], p[3]);
 }
 
 // One light's term of Renderer::phong_color (framework/renderer.cpp:142-163) without the
@@ -1216,8 +1243,57 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 	stat_add_tests(st, 3, tc);
 }
 
-template <bool PRIMARY, bool INTPOW>
-__global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) {
+// The shading kernel as a pipeline (see pipeline_wait): at the TOP of step k the wave
+//   - writes out what step k-1 produced: its child rays and shadow-ray records, which step k-1
+//     left compacted in a staging area in LDS, go to the queues with contiguous 16-byte stores,
+//     and its contribution is added to the pixels;
+//   - requests what step k+1 will read: the ray each hit of step k+1 belongs to (a gather through
+//     the hit record, which arrived a step earlier), the per-triangle record of a mesh hit, and
+//     the hit records of step k+2;
+// and then shades step k from registers.  The small tables every hit needs (leaf, matrices,
+// material) are read from copies in LDS when the scene's fit (LT), so that nothing in the body
+// of a step waits for global memory.
+constexpr int kLdsRoot = 16;    // frame-0 leaves, mesh frames and materials whose tables fit the LDS copies
+constexpr int kLdsFrames = 8;
+constexpr int kLdsMats = 32;
+constexpr int kStageLights = 2;  // lights whose shadow-ray records go through the staging area (further lights: stored directly)
+struct ShadeStage {              // per wave: the records of one step, compacted
+	float4 child_a[128], child_b[128];
+	float2 child_c[128];
+	float4 shadow_a[64 * kStageLights], shadow_b[64 * kStageLights];
+};
+template <bool LT>
+struct ShadeLds {
+	DevRootPrim prim[LT ? kLdsRoot : 1];
+	DevRootShade shade[LT ? kLdsRoot : 1];
+	DevXform xf[LT ? kLdsRoot : 1];
+	Mat16 fwinv[LT ? kLdsFrames : 1], fw[LT ? kLdsFrames : 1];
+	float4 mats[LT ? kLdsMats * 4 : 1];
+};
+template <class T>
+__device__ __forceinline__ void lds_copy(T* dst, const T* src, int count) {  // by the whole workgroup, 16 bytes per thread and round
+	static_assert(sizeof(T) % 16 == 0, "tables are copied in 16-byte pieces");
+	const int n = count * (int) (sizeof(T) / 16);
+	float4* d = reinterpret_cast<float4*>(dst);
+	const float4* g = reinterpret_cast<const float4*>(src);
+	for (int i = threadIdx.x; i < n; i += kBlock) d[i] = g[i];
+}
+
+template <bool PRIMARY, bool INTPOW, bool LT>
+__global__ __launch_bounds__(kBlock, 3) void k_shade(BounceArgs A) {
+	__shared__ ShadeLds<LT> lds;
+	__shared__ ShadeStage stage_mem[kBlock / 64];
+	if (LT) {
+		lds_copy(lds.prim, A.S.root_prims, A.S.n_root_prims);
+		lds_copy(lds.shade, A.S.root_shade, A.S.n_root_prims);
+		lds_copy(lds.xf, A.S.xforms, A.S.n_root_prims);
+		lds_copy(lds.fwinv, A.S.frame_winv, A.S.n_frames);
+		lds_copy(lds.fw, A.S.frame_w, A.S.n_frames);
+		lds_copy(lds.mats, A.S.mat_table, A.S.n_materials * 4);
+		__syncthreads();
+	}
+	const ShadeTables T = LT ? ShadeTables{lds.prim, lds.shade, lds.xf, lds.fwinv, lds.fw, lds.mats} : device_tables(A.S);
+	ShadeStage& stage = stage_mem[threadIdx.x >> 6];
 	const unsigned lane = lane_id();
 	const unsigned wave = wave_id();
 	const unsigned n = min(A.hit_count[wave], A.seg_cap);
@@ -1226,17 +1302,81 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 	const float4* const my_hits = A.hits + seg_base;
 	unsigned n_out = 0, n_shadow = 0;
 	unsigned cnt_shadow = 0, cnt_hits = 0;
-	// the hit record of a step is fetched one step ahead, so that its trip from memory runs
-	// beside the previous step's work instead of in front of this step's
-	const float4 none = make_float4(0.f, __int_as_float(-1), 0.f, 0.f);
-	float4 hr_next = lane < n ? my_hits[lane] : none;
-	for (unsigned k = 0; k < steps; ++k) {
-		const float4 hr = hr_next;
-		const bool hit = __float_as_int(hr.y) >= 0;
-		{
-			const unsigned r = (k + 1) * 64 + lane;
-			hr_next = r < n ? my_hits[r] : none;
+
+	// ---- requests (unconditional loads: a lane without a record reads a harmless place, see k_trace)
+	auto fetch_hit = [&](unsigned k) {
+		const unsigned r = k * 64 + lane;
+		float4 hr = my_hits[r < n ? r : 0u];
+		if (!(r < n)) hr = make_float4(0.f, __int_as_float(-1), 0.f, __uint_as_float(PRIMARY ? 0u : (unsigned) seg_base));
+		return hr;
+	};
+	struct RayRec {
+		float4 a, b;
+		float2 c;
+	};
+	auto fetch_ray = [&](const float4& hr, RayRec& r) {  // the ray behind a hit record (depth > 0)
+		if (PRIMARY) return;
+		const unsigned ref = __float_as_uint(hr.w);
+		r.a = A.in.a[ref];
+		r.b = A.in.b[ref];
+		r.c = A.in.c[ref];
+	};
+	auto fetch_info = [&](const float4& hr) {  // prim_info of the hit prim (any valid index for a lane without a hit)
+		const int id = __float_as_int(hr.y);
+		return A.S.prim_info[id < 0 ? 0 : id];
+	};
+
+	// ---- what a step leaves for the top of the next one
+	unsigned pend_children = 0, pend_child_at = 0;  // staged child rays and their place in this wave's segment of `out`
+	unsigned pend_shadows = 0, pend_shadow_at = 0;
+	unsigned pend_pix = 0;
+	f3 pend_contrib = {0, 0, 0};
+	bool pend_hit = false;
+	auto flush = [&]() {
+		for (unsigned i = lane; i < pend_children; i += 64) {
+			const size_t j = seg_base + pend_child_at + i;
+			A.out.a[j] = stage.child_a[i];
+			A.out.b[j] = stage.child_b[i];
+			A.out.c[j] = stage.child_c[i];
 		}
+		for (unsigned i = lane; i < pend_shadows; i += 64) {
+			const size_t j = seg_base + pend_shadow_at + i;
+			A.shadow.a[j] = stage.shadow_a[i];
+			A.shadow.b[j] = stage.shadow_b[i];
+		}
+		accumulate(A.accum, pend_pix, pend_contrib, pend_hit);
+		pend_children = pend_shadows = 0;
+		pend_hit = false;
+	};
+
+	if (steps == 0) {
+		if (lane == 0) {
+			A.out_count[wave] = 0;
+			A.shadow_count[wave] = 0;
+		}
+		return;
+	}
+	float4 hit_next = fetch_hit(0);  // hit records of the step after the current one
+	pipeline_wait();
+	RayRec ray_next;
+	ray_next.a = ray_next.b = make_float4(0.f, 0.f, 0.f, 0.f);
+	ray_next.c = make_float2(0.f, 0.f);
+	fetch_ray(hit_next, ray_next);
+	float4 info_next = fetch_info(hit_next);
+	float4 hit_cur = hit_next;
+	hit_next = fetch_hit(1);
+	for (unsigned k = 0; k < steps; ++k) {
+		pipeline_wait();
+		const float4 hr = hit_cur, info = info_next;
+		const RayRec ray = ray_next;
+		hit_cur = hit_next;
+		// ---- the burst: results of step k-1 out, records of steps k+1 / k+2 requested
+		flush();
+		fetch_ray(hit_cur, ray_next);
+		info_next = fetch_info(hit_cur);
+		hit_next = fetch_hit(k + 2);
+		// ---- step k
+		const bool hit = __float_as_int(hr.y) >= 0;
 		f3 o = {0, 0, 0}, d = {0, 0, -1}, w = {1, 1, 1};
 		unsigned pix = 0;
 		Surface sf;
@@ -1253,9 +1393,16 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 			const int where = __float_as_int(hr.z);
 			h.frame = where < 0 ? -where : 0;
 			h.slot = where < 0 ? 0 : where;
-			input_ray<PRIMARY>(A, __float_as_uint(hr.w), o, d, w, pix);
-			sf = surface_of(A.S, o, d, h);
-			Material M = load_material(A.S, h.id);
+			if (PRIMARY) {
+				input_ray<true>(A, __float_as_uint(hr.w), o, d, w, pix);
+			} else {
+				o = mk(ray.a.x, ray.a.y, ray.a.z);
+				d = mk(ray.a.w, ray.b.x, ray.b.y);
+				w = mk(ray.b.z, ray.b.w, ray.c.x);
+				pix = __float_as_uint(ray.c.y);
+			}
+			sf = surface_of(T, o, d, h, info);
+			const Material M = material_of(T, h, info);
 			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
 			kd = M.kd;
 			ks = M.ks;
@@ -1268,30 +1415,71 @@ __global__ __launch_bounds__(kBlock, INTPOW ? 4 : 3) void k_shade(BounceArgs A) 
 		}
 		// one shadow ray per light whose term can add something; its record carries the finished
 		// contribution weight * ((diffuse + specular) * opacity * k1)
+		pend_shadow_at = n_shadow;
 		for (int l = 0; l < A.S.n_lights; ++l) {
 			bool want = false;
-			float4 r[3];
+			float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
 			if (hit) {
-				LightTerm T;
-				want = light_term<INTPOW>(A.S, l, sf, kd, ks, mm, T);
-				f3 term = T.diffuse;
-				if (T.has_spec) term = term + T.spec;
-				f3 c = cmul(ws, (term * scale0) * k1);
+				LightTerm L;
+				want = light_term<INTPOW>(A.S, l, sf, kd, ks, mm, L);
+				f3 term = L.diffuse;
+				if (L.has_spec) term = term + L.spec;
+				const f3 c = cmul(ws, (term * scale0) * k1);
 				// (k_shadow forms the direction and distance to the light again, with the same operations)
-				r[0] = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(pix));
-				r[1] = make_float4(c.x, c.y, c.z, __int_as_float(l));
-				r[2] = r[1];
+				ra = make_float4(sf.pos.x, sf.pos.y, sf.pos.z, __uint_as_float(pix));
+				rb = make_float4(c.x, c.y, c.z, __int_as_float(l));
 			}
 			if (want) ++cnt_shadow;
-			emit_pair<false>(A.shadow, seg_base, A.seg_cap, n_shadow, want, r, false, r, A.counters);
+			const unsigned long long m = __ballot(want);
+			const unsigned cnt = __builtin_popcountll(m);
+			if (!cnt) continue;
+			const unsigned my = __builtin_popcountll(m & lanes_below(lane));
+			if (l < kStageLights) {
+				if (want) {
+					stage.shadow_a[pend_shadows + my] = ra;
+					stage.shadow_b[pend_shadows + my] = rb;
+				}
+				pend_shadows += cnt;
+			} else if (want && n_shadow + my < A.seg_cap) {  // (behind the staged ones of this step in the segment: their place is reserved)
+				A.shadow.a[seg_base + n_shadow + my] = ra;
+				A.shadow.b[seg_base + n_shadow + my] = rb;
+			}
+			n_shadow += cnt;
 		}
-		float4 r1[3], r2[3];
-		pack_child(refl, pix, r1);
-		pack_child(refr, pix, r2);
-		emit_pair(A.out, seg_base, A.seg_cap, n_out, refl.live, r1, refr.live, r2, A.counters);
-		// (last in the step: a later load of this wave cannot complete before an earlier atomic has)
-		accumulate(A.accum, pix, contrib, hit);
+		{
+			const unsigned long long m1 = __ballot(refl.live), m2 = __ballot(refr.live);
+			const unsigned long long lt = lanes_below(lane);
+			unsigned my = __builtin_popcountll(m1 & lt) + __builtin_popcountll(m2 & lt);
+			float4 r[3];
+			if (refl.live) {
+				pack_child(refl, pix, r);
+				stage.child_a[my] = r[0];
+				stage.child_b[my] = r[1];
+				stage.child_c[my] = make_float2(r[2].x, r[2].y);
+				++my;
+			}
+			if (refr.live) {
+				pack_child(refr, pix, r);
+				stage.child_a[my] = r[0];
+				stage.child_b[my] = r[1];
+				stage.child_c[my] = make_float2(r[2].x, r[2].y);
+			}
+			pend_children = __builtin_popcountll(m1) + __builtin_popcountll(m2);
+			pend_child_at = n_out;
+			n_out += pend_children;
+		}
+		// the host's sizing rules an overflow out; kept as a tripwire: what would not fit is dropped and flagged
+		if (n_out > A.seg_cap || n_shadow > A.seg_cap) {
+			if (lane == 0) atomicAdd(&A.counters->overflow, 1ull);
+			pend_children = pend_child_at < A.seg_cap ? min(pend_children, A.seg_cap - pend_child_at) : 0u;
+			pend_shadows = pend_shadow_at < A.seg_cap ? min(pend_shadows, A.seg_cap - pend_shadow_at) : 0u;
+		}
+		pend_pix = pix;
+		pend_contrib = contrib;
+		pend_hit = hit;
 	}
+	pipeline_wait();
+	flush();
 	if (lane == 0) {
 		A.out_count[wave] = n_out;
 		A.shadow_count[wave] = n_shadow;
