@@ -711,7 +711,10 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 				return ip ? (lt ? k_shade<P, true, true> : k_shade<P, true, false>) : (lt ? k_shade<P, false, true> : k_shade<P, false, false>);
 			};
 			auto kern = d == 0 ? pick(std::true_type{}) : pick(std::false_type{});
-			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
+			A.stage_children = sc->branching ? 128u : 64u;
+			A.stage_lights = (unsigned) std::min(std::max(sc->dev.n_lights, 0), kStageLights);
+			const size_t stage_bytes = (size_t) (kBlock / 64) * shade_stage_f4(A.stage_children, A.stage_lights) * sizeof(float4);
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), stage_bytes, stream, A);
 		}
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {

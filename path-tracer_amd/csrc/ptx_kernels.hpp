@@ -928,6 +928,8 @@ struct BounceArgs {
 	// staged pipeline only
 	RayQueue shadow;           // a = (o.xyz, bits(pixel))  b = (contribution rgb, bits(light)); plane c unused (32 B per shadow ray)
 	unsigned* shadow_count;
+	unsigned stage_children;   // k_shade's staging area per wave: child rays (64, or 128 where a material spawns two) ...
+	unsigned stage_lights;     // ... and lights whose shadow-ray records are staged (<= kStageLights)
 	float4* hits;              // hit records: (t, bits(prim id), bits(where), bits(ray))
 	                           // ray = the sample's index in the batch (depth 0) or the ray's slot in `in`
 	unsigned* hit_count;
@@ -1257,11 +1259,16 @@ constexpr int kLdsRoot = 16;    // frame-0 leaves, mesh frames and materials who
 constexpr int kLdsFrames = 8;
 constexpr int kLdsMats = 32;
 constexpr int kStageLights = 2;  // lights whose shadow-ray records go through the staging area (further lights: stored directly)
-struct ShadeStage {              // per wave: the records of one step, compacted
-	float4 child_a[128], child_b[128];
-	float2 child_c[128];
-	float4 shadow_a[64 * kStageLights], shadow_b[64 * kStageLights];
+// Staging area of one wave, cut from the launch's dynamic LDS: room for the records ONE step can
+// produce on this scene (BounceArgs::stage_children = 64 or 128 child rays, stage_lights x 64
+// shadow-ray records), so that a scene with one light and one-child materials leaves the LDS to
+// a fourth workgroup per CU.
+struct ShadeStage {
+	float4 *child_a, *child_b;
+	float2* child_c;
+	float4 *shadow_a, *shadow_b;
 };
+__host__ __device__ constexpr unsigned shade_stage_f4(unsigned children, unsigned lights) { return children * 2 + children / 2 + lights * 64 * 2; }  // float4 per wave
 template <bool LT>
 struct ShadeLds {
 	DevRootPrim prim[LT ? kLdsRoot : 1];
@@ -1270,30 +1277,58 @@ struct ShadeLds {
 	Mat16 fwinv[LT ? kLdsFrames : 1], fw[LT ? kLdsFrames : 1];
 	float4 mats[LT ? kLdsMats * 4 : 1];
 };
-template <class T>
-__device__ __forceinline__ void lds_copy(T* dst, const T* src, int count) {  // by the whole workgroup, 16 bytes per thread and round
-	static_assert(sizeof(T) % 16 == 0, "tables are copied in 16-byte pieces");
-	const int n = count * (int) (sizeof(T) / 16);
-	float4* d = reinterpret_cast<float4*>(dst);
-	const float4* g = reinterpret_cast<const float4*>(src);
-	for (int i = threadIdx.x; i < n; i += kBlock) d[i] = g[i];
+// Fills the LDS copies: the six tables as one list of 16-byte pieces dealt to the threads of the
+// workgroup, all loads of a round of pieces in flight together (a loop per table waited for
+// memory six times in a row).
+template <bool LT>
+__device__ __forceinline__ void fill_shade_lds(ShadeLds<LT>& lds, const DevScene& S) {
+	const int np[6] = {S.n_root_prims * (int) (sizeof(DevRootPrim) / 16), S.n_root_prims * (int) (sizeof(DevRootShade) / 16),
+	                   S.n_root_prims * (int) (sizeof(DevXform) / 16),    S.n_frames * (int) (sizeof(Mat16) / 16),
+	                   S.n_frames * (int) (sizeof(Mat16) / 16),           S.n_materials * 4};
+	const float4* const src[6] = {reinterpret_cast<const float4*>(S.root_prims), reinterpret_cast<const float4*>(S.root_shade),
+	                              reinterpret_cast<const float4*>(S.xforms),     reinterpret_cast<const float4*>(S.frame_winv),
+	                              reinterpret_cast<const float4*>(S.frame_w),    S.mat_table};
+	float4* const dst[6] = {reinterpret_cast<float4*>(lds.prim),  reinterpret_cast<float4*>(lds.shade), reinterpret_cast<float4*>(lds.xf),
+	                        reinterpret_cast<float4*>(lds.fwinv), reinterpret_cast<float4*>(lds.fw),    lds.mats};
+	const int total = np[0] + np[1] + np[2] + np[3] + np[4] + np[5];
+	for (int p0 = 0; p0 < total; p0 += 2 * kBlock) {
+		float4 v[2];
+		float4* to[2] = {nullptr, nullptr};
+#pragma unroll
+		for (int r = 0; r < 2; ++r) {
+			int p = p0 + r * kBlock + (int) threadIdx.x;
+			v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (p < total) {
+				int t = 0;
+				while (p >= np[t]) p -= np[t++];
+				v[r] = src[t][p];
+				to[r] = dst[t] + p;
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < 2; ++r)
+			if (to[r]) *to[r] = v[r];
+	}
 }
 
 template <bool PRIMARY, bool INTPOW, bool LT>
-__global__ __launch_bounds__(kBlock, 3) void k_shade(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? 4 : 3) void k_shade(BounceArgs A) {
 	__shared__ ShadeLds<LT> lds;
-	__shared__ ShadeStage stage_mem[kBlock / 64];
+	extern __shared__ float4 stage_mem[];
 	if (LT) {
-		lds_copy(lds.prim, A.S.root_prims, A.S.n_root_prims);
-		lds_copy(lds.shade, A.S.root_shade, A.S.n_root_prims);
-		lds_copy(lds.xf, A.S.xforms, A.S.n_root_prims);
-		lds_copy(lds.fwinv, A.S.frame_winv, A.S.n_frames);
-		lds_copy(lds.fw, A.S.frame_w, A.S.n_frames);
-		lds_copy(lds.mats, A.S.mat_table, A.S.n_materials * 4);
+		fill_shade_lds(lds, A.S);
 		__syncthreads();
 	}
 	const ShadeTables T = LT ? ShadeTables{lds.prim, lds.shade, lds.xf, lds.fwinv, lds.fw, lds.mats} : device_tables(A.S);
-	ShadeStage& stage = stage_mem[threadIdx.x >> 6];
+	ShadeStage stage;
+	{
+		float4* p = stage_mem + (threadIdx.x >> 6) * shade_stage_f4(A.stage_children, A.stage_lights);
+		stage.child_a = p;
+		stage.child_b = p + A.stage_children;
+		stage.child_c = reinterpret_cast<float2*>(p + 2 * A.stage_children);
+		stage.shadow_a = p + 2 * A.stage_children + A.stage_children / 2;
+		stage.shadow_b = stage.shadow_a + 64 * A.stage_lights;
+	}
 	const unsigned lane = lane_id();
 	const unsigned wave = wave_id();
 	const unsigned n = min(A.hit_count[wave], A.seg_cap);
@@ -1434,7 +1469,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_shade(BounceArgs A) {
 			const unsigned cnt = __builtin_popcountll(m);
 			if (!cnt) continue;
 			const unsigned my = __builtin_popcountll(m & lanes_below(lane));
-			if (l < kStageLights) {
+			if (l < (int) A.stage_lights) {
 				if (want) {
 					stage.shadow_a[pend_shadows + my] = ra;
 					stage.shadow_b[pend_shadows + my] = rb;
