@@ -522,6 +522,9 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(S.ambient, D->ambient, sizeof S.ambient);
 	std::memcpy(S.root_min, D->frames[0].bounds_min, sizeof S.root_min);
 	std::memcpy(S.root_max, D->frames[0].bounds_max, sizeof S.root_max);
+	S.bounds_clean = 1;  // (frame-0 leaves and mesh frames with a non-finite number were dropped above)
+	for (int k = 0; k < 3; ++k)
+		if (std::isnan(S.root_min[k]) || std::isnan(S.root_max[k])) S.bounds_clean = 0;
 
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
 	if (queue_bytes == 0) {  // a third of what the device has free now, at most 96 GiB (more was measured to add nothing)

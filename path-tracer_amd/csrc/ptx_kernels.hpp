@@ -94,6 +94,7 @@ struct DevScene {
 	PTX_KPTR(float4) root_bound_k;  // per frame-0 leaf: padded bounding box in frame-0 space, 2 x float4 (lo, hi)
 	int32_t n_root_prims, n_frames, n_lights, n_prims, n_materials;
 	int32_t has_plain_sphere;
+	int32_t bounds_clean;    // no NaN in the root's or any mesh's bounds, no NaN / infinity in a frame-0 box or its translation
 	int32_t root_bvh;        // != 0: the leaves of frame 0 are many and sit under a BVH of their own (root_walk)
 	int32_t root_bvh_root;   // its root reference
 	int32_t root_node_base;  // first float4 of its nodes in `nodes`
@@ -305,12 +306,19 @@ struct RayPre {
 	float len;  // length(d)
 	f3 finv;    // finite reciprocal of d and -o * finv: the conservative bounding-box filter only
 	f3 fnoi;
+	bool clean;  // every ray of the wave is clean (box_slab_clean) and so are the scene's bounds: the same for all lanes
 };
+// Box::intersect(Ray, float&) in frame-0 space with the ray's shared reciprocals
+__device__ __forceinline__ bool box_test(f3 lo, f3 hi, f3 o, f3 d, const RayPre& pre, float& t) {
+	if (pre.clean) return box_slab_clean(lo, hi, o, pre.inv, t);
+	return box_slab_inv(lo, hi, o, d, pre.inv, t);
+}
 __device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 o, f3 d) {
 	RayPre r;
 	r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 	r.finv = mk(bvh_rcp(d.x), bvh_rcp(d.y), bvh_rcp(d.z));
 	r.fnoi = mk(-(o.x * r.finv.x), -(o.y * r.finv.y), -(o.z * r.finv.z));
+	r.clean = S.bounds_clean && __ballot(!ray_is_clean(o, d, r.inv)) == 0;
 	r.dn = mk(0, 0, 0);
 	r.len = 0;
 	if (S.has_plain_sphere) {
@@ -349,7 +357,7 @@ __device__ __forceinline__ bool root_prim_t(const DevScene& S, const DevRootPrim
 	if (P.kind_flags & kPlain) {
 		f3 lo = o + ld3(P.tinv);
 		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
-		if (kind == PTX_BOX) return box_slab_inv(ld3(P.p), ld3(P.p + 3), lo, d, pre.inv, t);
+		if (kind == PTX_BOX) return box_test(ld3(P.p), ld3(P.p + 3), lo, d, pre, t);
 		return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, d, t);
 	}
 	const Mat16 Wi = kload(reinterpret_cast<PTX_KPTR(Mat16)>(S.xforms_k + P.xform));
@@ -386,7 +394,7 @@ __device__ __forceinline__ bool root_prim_t_lane(const DevScene& S, int slot, f3
 	if (kf & kPlain) {
 		f3 lo = o + ld3(P.tinv);
 		if (kind == PTX_SPHERE) return sphere_t_pre(ld3(P.p), P.p[3], lo, pre.dn, pre.len, t);
-		if (kind == PTX_BOX) return box_slab_inv(ld3(P.p), ld3(P.p + 3), lo, d, pre.inv, t);
+		if (kind == PTX_BOX) return box_test(ld3(P.p), ld3(P.p + 3), lo, d, pre, t);
 		return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, d, t);
 	}
 	const float* Wi = S.xforms[slot].winv;
@@ -485,7 +493,7 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	best.slot = 0;
 	float unused;
 	tc.slab();
-	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, unused)) return false;
+	if (!box_test(ld3(S.root_min), ld3(S.root_max), o, d, pre, unused)) return false;
 	if (RB && S.root_bvh) {
 		root_walk<false>(S, o, d, pre, stk, best, 0.0f, tc);
 		return true;
@@ -512,7 +520,7 @@ __device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, co
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
 		tc.slab();
-		if (box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) mask |= 1u << f;
+		if (box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, unused)) mask |= 1u << f;
 	}
 	return mask;
 }
@@ -526,7 +534,7 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 			if (!(known >> f & 1u)) continue;
 		} else {
 			tc.slab();
-			if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, unused)) continue;
+			if (!box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, unused)) continue;
 		}
 		f3 lo, ld;
 		frame_ray(S, F, f, o, d, lo, ld, tc);
@@ -548,7 +556,7 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 	float t;
 	RayPre pre = ray_pre(S, o, d);
 	tc.slab();
-	if (!box_slab_inv(ld3(S.root_min), ld3(S.root_max), o, d, pre.inv, t)) return false;
+	if (!box_test(ld3(S.root_min), ld3(S.root_max), o, d, pre, t)) return false;
 	Hit dummy;
 	if (RB && S.root_bvh) {
 		if (root_walk<true>(S, o, d, pre, stk, dummy, range, tc)) return true;
@@ -565,7 +573,7 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
 		tc.slab();
-		if (!box_slab_inv(ld3(F.bmin), ld3(F.bmax), o, d, pre.inv, t)) continue;
+		if (!box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, t)) continue;
 		f3 lo, ld;
 		frame_ray(S, F, f, o, d, lo, ld, tc);
 		if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range, tc)) return true;
