@@ -253,6 +253,22 @@ PtxStatus ptx_render_image(PtxScene* scene, const PtxRenderParams* params, float
                            double* seconds, PtxStats* stats);
 
 /*
+ * Renderer::render's fan-out over hardware threads (framework/renderer.cpp:39-53), over GPUs:
+ * one image rendered by n_scenes GPUs of this process.  scenes[r] is the same scene created on
+ * GPU r (ptx_scene_create once per device; two scenes on one device also work, for rehearsals
+ * on a one-GPU machine).  The call starts one host thread per scene; worker r renders ALL pixels
+ * for the r-th of n_scenes contiguous slices of [sample_begin, sample_end) into a buffer on its
+ * own GPU; the buffers are then summed on scenes[0]'s GPU (every peer's buffer comes over its
+ * own xGMI link and is added by a kernel), resolved there, and copied to the host arrays like
+ * ptx_render_image does.  stats: n_scenes entries (one per worker) or NULL.  seconds: wall
+ * time of the whole call.  Blocking; the workers' errors come back as this call's.
+ * Processes that hold one GPU each (torch.distributed, MPI) use ptx_render_accumulate with
+ * their own sample range and sum the buffers with one RCCL reduce instead.
+ */
+PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, const PtxRenderParams* params, float* color,
+                                 uint8_t* rgb8, double* seconds, PtxStats* stats);
+
+/*
  * scene.root->intersect(ray) for n rays (framework/renderer.cpp:109, shape.hpp:28).
  * Host arrays; origins/dirs are n*3 floats.  prim = index into PtxSceneDesc::prims or -1;
  * t = HitPoint::distance; pos / normal / raydir = HitPoint::position / surface_normal /
@@ -280,6 +296,36 @@ PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, u
  */
 PtxStatus ptx_write_ppm_binary(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
 PtxStatus ptx_write_pfm(const char* path, const float* color, uint32_t width, uint32_t height);
+
+/*
+ * An image file written BESIDE the rendering (PpmWriter::save, framework/ppmwriter.cpp:55-76,
+ * blocks the reference's render thread; at 3840x2160 its text is 90 MB).  d_pixels is a DEVICE
+ * buffer: the flipped 8-bit rows of ptx_resolve for the two PPM formats, its float colour buffer
+ * for PFM.  The call queues a device-to-host copy into pinned memory on `stream` and returns; a
+ * worker thread waits for the copy, formats and writes the file.  The caller may go on using the
+ * stream at once (work queued behind the copy may overwrite d_pixels) - e.g. render the next
+ * sample range while the preview of the last one is written.  ptx_write_wait joins the worker,
+ * frees the job and returns the status of the write; every job must be waited for once.
+ */
+typedef enum PtxImageFormat { PTX_IMAGE_PPM_ASCII = 0, PTX_IMAGE_PPM_BINARY = 1, PTX_IMAGE_PFM = 2 } PtxImageFormat;
+typedef struct PtxWriteJob PtxWriteJob;
+PtxStatus ptx_write_image_async(const char* path, PtxImageFormat format, int device, const void* d_pixels, uint32_t width,
+                                uint32_t height, void* stream, PtxWriteJob** job);
+PtxStatus ptx_write_wait(PtxWriteJob* job);
+
+/*
+ * Checkpoint of a render in progress (the reference saves nothing before the image is complete,
+ * framework/renderer.cpp:58): the accumulation buffer of ptx_render_accumulate (device, w*h*3
+ * floats) together with the range of per-pixel samples it holds, as one little-endian file
+ * (32-byte header + the floats), written under a temporary name and renamed.  ptx_accum_load
+ * checks that the file is for this image size and aa_steps, fills d_accum and reports the range;
+ * rendering the remaining samples into the loaded buffer gives the image an uninterrupted render
+ * gives.  Both calls wait for `stream`.
+ */
+PtxStatus ptx_accum_save(const char* path, int device, const float* d_accum, uint32_t width, uint32_t height, uint32_t aa_steps,
+                         uint32_t sample_begin, uint32_t sample_end, void* stream);
+PtxStatus ptx_accum_load(const char* path, int device, float* d_accum, uint32_t width, uint32_t height, uint32_t aa_steps,
+                         uint32_t* sample_begin, uint32_t* sample_end, void* stream);
 
 /*
  * Profiling level 1: ptx_render_accumulate brackets every bounce-kernel launch with a pair of

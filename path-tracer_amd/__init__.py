@@ -30,7 +30,8 @@ STATUS_NAMES = {0: "PTX_OK", 1: "PTX_ERR_INVALID", 2: "PTX_ERR_UNSUPPORTED", 3: 
 PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
     "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_write_ppm_binary", "ptx_write_pfm", "ptx_scene_info", "ptx_jitter",
-    "ptx_scene_set_profiling", "ptx_render_accumulate_static",
+    "ptx_scene_set_profiling", "ptx_render_accumulate_static", "ptx_render_image_multi", "ptx_write_image_async", "ptx_write_wait",
+    "ptx_accum_save", "ptx_accum_load",
 ]
 
 
@@ -130,6 +131,11 @@ def ptx_lib():
     L.ptx_scene_destroy.restype = None
     L.ptx_render_accumulate.argtypes = [vp, C.POINTER(PtxRenderParams), vp, vp, C.c_int, C.POINTER(PtxStats)]
     L.ptx_render_accumulate_static.argtypes = L.ptx_render_accumulate.argtypes
+    L.ptx_render_image_multi.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(PtxRenderParams), vp, vp, C.POINTER(C.c_double), C.POINTER(PtxStats)]
+    L.ptx_write_image_async.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, C.c_uint32, C.c_uint32, vp, C.POINTER(vp)]
+    L.ptx_write_wait.argtypes = [vp]
+    L.ptx_accum_save.argtypes = [C.c_char_p, C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.ptx_accum_load.argtypes = [C.c_char_p, C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp]
     L.ptx_resolve.argtypes = [C.c_int, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.ptx_render_image.argtypes = [vp, C.POINTER(PtxRenderParams), vp, vp, C.POINTER(C.c_double), C.POINTER(PtxStats)]
     L.ptx_intersect.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
@@ -163,6 +169,13 @@ def host_lib():
     H.pth_prim_path.argtypes = [C.c_void_p, C.c_int]
     H.pth_tree_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     H.pth_render_file.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_char_p, C.c_void_p, C.POINTER(C.c_double)]
+    H.pth_renderer_create.restype = C.c_void_p
+    H.pth_renderer_create.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_char_p]
+    H.pth_renderer_destroy.restype = None
+    H.pth_renderer_destroy.argtypes = [C.c_void_p]
+    H.pth_renderer_options.restype = None
+    H.pth_renderer_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    H.pth_renderer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     H.pth_shape_matrices.restype = None
     H.pth_shape_matrices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     H._typed = True
@@ -284,6 +297,34 @@ class HostScene:
         return color, sec.value
 
 
+class HostRenderer:
+    """The host-side C++ Renderer (the reference's class, rendering on the GPUs) kept across calls."""
+
+    def __init__(self, w, h, aa, bounces, ppm_path=None, first_device=-1, n_devices=0, keep_scene=False):
+        self._H = host_lib()
+        self.w, self.h = w, h
+        self.handle = self._H.pth_renderer_create(w, h, aa, bounces, os.fspath(ppm_path).encode() if ppm_path else None)
+        self._H.pth_renderer_options(self.handle, first_device, n_devices, int(keep_scene))
+
+    def render(self, host_scene):
+        color = np.zeros((self.h, self.w, 3), np.float32)
+        dev, setup = C.c_double(0), C.c_double(0)
+        if self._H.pth_renderer_render(self.handle, host_scene.handle, _ptr(color), C.byref(dev), C.byref(setup)) != 0:
+            raise RuntimeError(self._H.pth_last_error().decode())
+        return dict(color=color, seconds=dev.value, setup_seconds=setup.value)
+
+    def close(self):
+        if self.handle:
+            self._H.pth_renderer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceScene:
     """A scene resident on one GPU (ptx_scene_create)."""
 
@@ -354,6 +395,47 @@ class DeviceScene:
         t = np.zeros(w * h, np.float32)
         _check(self.L.ptx_primary_hits(self.handle, C.byref(rp), sample, _ptr(prim), _ptr(t)))
         return prim, t
+
+
+IMAGE_FORMATS = {"ppm": 0, "ppm_binary": 1, "pfm": 2}
+
+
+def render_image_multi(scenes, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0):
+    """ptx_render_image_multi over a list of DeviceScene objects (one per GPU)."""
+    L = ptx_lib()
+    rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline, jitter_seed)
+    color = np.zeros((h, w, 3), np.float32)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    sec = C.c_double(0)
+    stats = (PtxStats * len(scenes))()
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    _check(L.ptx_render_image_multi(handles, len(scenes), C.byref(rp), _ptr(color), _ptr(rgb), C.byref(sec), stats))
+    return dict(color=color, rgb=rgb, seconds=sec.value, stats=[s.as_dict() for s in stats])
+
+
+class ImageWrite:
+    """ptx_write_image_async: the file is written by a worker thread of the library; wait() joins it."""
+
+    def __init__(self, path, fmt, device, d_pixels_ptr, w, h, stream=None):
+        self.L = ptx_lib()
+        self.job = C.c_void_p()
+        _check(self.L.ptx_write_image_async(os.fspath(path).encode(), IMAGE_FORMATS[fmt], device, C.c_void_p(d_pixels_ptr), w, h,
+                                            C.c_void_p(stream or 0), C.byref(self.job)))
+
+    def wait(self):
+        job, self.job = self.job, None
+        if job:
+            _check(self.L.ptx_write_wait(job))
+
+
+def accum_save(path, device, d_accum_ptr, w, h, aa, sample_begin, sample_end, stream=None):
+    _check(ptx_lib().ptx_accum_save(os.fspath(path).encode(), device, C.c_void_p(d_accum_ptr), w, h, aa, sample_begin, sample_end, C.c_void_p(stream or 0)))
+
+
+def accum_load(path, device, d_accum_ptr, w, h, aa, stream=None):
+    b, e = C.c_uint32(0), C.c_uint32(0)
+    _check(ptx_lib().ptx_accum_load(os.fspath(path).encode(), device, C.c_void_p(d_accum_ptr), w, h, aa, C.byref(b), C.byref(e), C.c_void_p(stream or 0)))
+    return b.value, e.value
 
 
 def write_ppm(path, rgb):

@@ -93,4 +93,43 @@ int pth_render_file(void* h, unsigned w, unsigned hgt, unsigned aa, unsigned bou
 	return -1;
 }
 
+// The same through a Renderer object that lives across calls (keep_scene, GPU selection).
+void* pth_renderer_create(unsigned w, unsigned hgt, unsigned aa, unsigned bounces, const char* ppm_path) {
+	auto* r = new Renderer{w, hgt, ppm_path ? ppm_path : "", aa, bounces};
+	r->set_output(ppm_path != nullptr);
+	return r;
+}
+void pth_renderer_destroy(void* r) { delete static_cast<Renderer*>(r); }
+// first_device < 0: leave the GPU selection alone; n_devices 0 = all from first_device on
+void pth_renderer_options(void* r, int first_device, int n_devices, int keep_scene) {
+	auto* R = static_cast<Renderer*>(r);
+	if (first_device >= 0) {
+		if (n_devices == 1) R->set_device(first_device);
+		else R->set_devices(n_devices);
+	}
+	R->keep_scene(keep_scene != 0);
+}
+int pth_renderer_render(void* r, void* h, float* color, double* device_seconds, double* setup_seconds) {
+	auto* R = static_cast<Renderer*>(r);
+	try {
+		R->render(static_cast<HostScene*>(h)->scene);
+		if (color) {
+			auto const& cb = R->color_buffer();
+			for (size_t i = 0; i < cb.size(); ++i) {
+				color[3 * i] = cb[i].r;
+				color[3 * i + 1] = cb[i].g;
+				color[3 * i + 2] = cb[i].b;
+			}
+		}
+		if (device_seconds) *device_seconds = R->device_seconds();
+		if (setup_seconds) *setup_seconds = R->setup_seconds();
+		return 0;
+	} catch (const char* msg) {
+		g_err = msg;
+	} catch (SceneError const& e) {
+		g_err = e.message;
+	}
+	return -1;
+}
+
 }  // extern "C"

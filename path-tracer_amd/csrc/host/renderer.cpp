@@ -26,20 +26,11 @@ void PpmWriter::save(std::string const& file) {
 	file_ = file;
 	save();
 }
-void PpmWriter::save() {  // framework/ppmwriter.cpp:55-76
-	std::string text = "P3 " + std::to_string((unsigned int) width_) + " " + std::to_string((unsigned int) height_) + " 255 \n";
-	text.reserve(data_.size() * 4 + 64);
-	std::size_t pos = 1;
-	for (auto it = data_.begin(); it < data_.end(); ++it, ++pos) {
-		text += std::to_string((int) *it);
-		text += ' ';
-		if (pos > 18) {
-			text += '\n';
-			pos = 0;
-		}
-	}
-	std::ofstream out(file_.c_str(), std::ios::out | std::ios::binary);
-	out.write(text.data(), (std::streamsize) text.size());
+void PpmWriter::save() {  // framework/ppmwriter.cpp:55-76: the same text, put together by the library's writer
+	std::vector<unsigned char> bytes(data_.size());
+	for (std::size_t i = 0; i < data_.size(); ++i) bytes[i] = (unsigned char) data_[i];  // (write() stores 0..255)
+	if (ptx_write_ppm(file_.c_str(), bytes.data(), (uint32_t) width_, (uint32_t) height_) != PTX_OK)
+		std::cerr << "PpmWriter::save : " << ptx_last_error() << "\n";  // (the reference ignores a file it cannot open)
 }
 
 // ---------------------------------------------------------------- Renderer
@@ -47,21 +38,44 @@ Renderer::Renderer(unsigned w, unsigned h, std::string const& file, unsigned aa_
     : width_(w), height_(h), color_buffer_(w * h, Color{0.0, 0.0, 0.0}), filename_(file), ppm_(width_, height_), aa_steps_(aa_steps),
       max_ray_bounces_(max_ray_bounces) {}
 
+Renderer::~Renderer() { drop_scene(); }
+
+void Renderer::drop_scene() {
+	for (PtxScene* s : dev_scenes_) ptx_scene_destroy(s);
+	dev_scenes_.clear();
+	kept_root_ = nullptr;
+}
+
 void Renderer::render(Scene const& scene) {
 	auto start = std::chrono::steady_clock::now();
-	PtxScene* dev_scene = nullptr;
 	auto raise = [&](std::string msg) {
-		if (dev_scene) ptx_scene_destroy(dev_scene);
+		drop_scene();
 		error_ = std::move(msg);
 		throw static_cast<const char*>(error_.c_str());
 	};
-	FlatScene flat;
-	try {
-		flat = flatten_scene(scene);
-	} catch (SceneError const& e) {
-		raise(e.message);
+	setup_seconds_ = 0;
+	if (!(keep_ && kept_root_ == scene.root.get() && !dev_scenes_.empty())) {
+		drop_scene();
+		FlatScene flat;
+		try {
+			flat = flatten_scene(scene);
+		} catch (SceneError const& e) {
+			raise(e.message);
+		}
+		const int visible = ptx_device_count();
+		if (visible < 1) raise("no gfx950 GPU: this Renderer has no CPU path");
+		int n = n_devices_ <= 0 ? visible - first_device_ : n_devices_;
+		if (first_device_ < 0 || first_device_ >= visible || n < 1 || first_device_ + n > visible) raise("the GPUs asked for are not there");
+		// every GPU renders at least one sample of every pixel
+		n = (int) std::min<unsigned long long>((unsigned long long) n, (unsigned long long) aa_steps_ * aa_steps_);
+		for (int k = 0; k < n; ++k) {
+			PtxScene* s = nullptr;
+			if (ptx_scene_create(&flat.desc, first_device_ + k, 0, &s) != PTX_OK) raise(ptx_last_error());
+			dev_scenes_.push_back(s);
+		}
+		kept_root_ = scene.root.get();
+		setup_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 	}
-	if (ptx_scene_create(&flat.desc, device_, 0, &dev_scene) != PTX_OK) raise(ptx_last_error());
 	PtxRenderParams rp{};
 	rp.width = width_;
 	rp.height = height_;
@@ -71,9 +85,18 @@ void Renderer::render(Scene const& scene) {
 	rp.sample_end = aa_steps_ * aa_steps_;
 	std::vector<float> color((size_t) width_ * height_ * 3);
 	std::vector<unsigned char> rows((size_t) width_ * height_ * 3);
-	if (ptx_render_image(dev_scene, &rp, color.data(), rows.data(), &device_seconds_, &stats_) != PTX_OK) raise(ptx_last_error());
-	ptx_scene_destroy(dev_scene);
-	dev_scene = nullptr;
+	std::vector<PtxStats> per_gpu(dev_scenes_.size());
+	if (ptx_render_image_multi(dev_scenes_.data(), (int32_t) dev_scenes_.size(), &rp, color.data(), rows.data(), &device_seconds_, per_gpu.data()) != PTX_OK)
+		raise(ptx_last_error());
+	stats_ = per_gpu[0];  // the work of all GPUs together (times: the first GPU's)
+	for (size_t k = 1; k < per_gpu.size(); ++k) {
+		stats_.samples += per_gpu[k].samples;
+		stats_.trace_rays += per_gpu[k].trace_rays;
+		stats_.shadow_rays += per_gpu[k].shadow_rays;
+		stats_.shaded_hits += per_gpu[k].shaded_hits;
+		stats_.launches += per_gpu[k].launches;
+	}
+	if (!keep_) drop_scene();
 	for (size_t i = 0; i < color_buffer_.size(); ++i) color_buffer_[i] = Color{color[3 * i], color[3 * i + 1], color[3 * i + 2]};
 	ppm_.set_rows(rows.data());
 	auto end = std::chrono::steady_clock::now();

@@ -21,9 +21,24 @@ public:
 	inline std::vector<Color> const& color_buffer() const { return color_buffer_; }
 	[[nodiscard]] float* pixel_buffer() const;
 
+	~Renderer();
+	Renderer(Renderer const&) = delete;
+	Renderer& operator=(Renderer const&) = delete;
+
 	// additions (no counterpart in the reference)
-	void set_device(int device) { device_ = device; }
+	// Which GPUs render() uses.  The reference spreads an image over every hardware thread
+	// (framework/renderer.cpp:39); the default here is every visible GPU, each taking a slice of
+	// the per-pixel samples (ptx_render_image_multi).  set_device(d) = GPU d only; set_devices(n) =
+	// the first n GPUs (0 = all).
+	void set_device(int device) { first_device_ = device; n_devices_ = 1; drop_scene(); }
+	void set_devices(int n) { first_device_ = 0; n_devices_ = n; drop_scene(); }
+	// keep = true: the flattened scene stays on the GPUs after render() and the next render() of
+	// the SAME Scene object (same root) skips flattening, BVH build and upload.  The caller then
+	// promises not to change the scene in between, or calls drop_scene() after changing it.
+	void keep_scene(bool keep) { keep_ = keep; if (!keep) drop_scene(); }
+	void drop_scene();
 	void set_output(bool save_ppm) { save_ppm_ = save_ppm; }
+	double setup_seconds() const { return setup_seconds_; }  // flatten + upload part of the last render() (0 when the kept scene was used)
 	PtxStats const& stats() const { return stats_; }
 	double device_seconds() const { return device_seconds_; }
 
@@ -35,7 +50,11 @@ private:
 	PpmWriter ppm_;
 	unsigned aa_steps_;
 	unsigned max_ray_bounces_;
-	int device_ = 0;
+	int first_device_ = 0, n_devices_ = 0;
+	bool keep_ = false;
+	const void* kept_root_ = nullptr;
+	std::vector<PtxScene*> dev_scenes_;
+	double setup_seconds_ = 0;
 	bool save_ppm_ = true;
 	PtxStats stats_{};
 	double device_seconds_ = 0;

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -34,6 +35,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -1021,24 +1023,37 @@ PtxStatus ptx_primary_hits(PtxScene* sc, const PtxRenderParams* rp, uint32_t sam
 	return run_intersect(sc, A, (int64_t) rp->width * rp->height, prim, t, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
+// PpmWriter::save (framework/ppmwriter.cpp:61-73): header, then "<value> " with a newline after
+// every 19th value.  The 256 possible tokens are formed once; a 3840x2160 image (25 M values,
+// about 90 MB of text) is then put together at memory speed instead of 25 M number formattings.
+static std::string ppm_text(const uint8_t* rgb8, uint32_t w, uint32_t h) {
+	char tok[256][4];
+	uint8_t len[256];
+	for (int v = 0; v < 256; ++v) len[v] = (uint8_t) std::snprintf(tok[v], sizeof tok[v], "%d", v);
+	std::string s = "P3 " + std::to_string(w) + " " + std::to_string(h) + " 255 \n";
+	const size_t n = (size_t) w * h * 3, head = s.size();
+	s.resize(head + n * 4 + n / 19 + 8);
+	char* out = &s[head];
+	size_t pos = 1;
+	for (size_t i = 0; i < n; ++i, ++pos) {
+		const uint8_t v = rgb8[i];
+		std::memcpy(out, tok[v], 3);
+		out += len[v];
+		*out++ = ' ';
+		if (pos > 18) {
+			*out++ = '\n';
+			pos = 0;
+		}
+	}
+	s.resize((size_t) (out - s.data()));
+	return s;
+}
+
 PtxStatus ptx_write_ppm(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
 	if (!path || !rgb8) return fail(PTX_ERR_INVALID, "path/rgb8 is NULL");
 	FILE* f = std::fopen(path, "wb");
 	if (!f) return fail(PTX_ERR_INVALID, std::string("cannot open ") + path);
-	// framework/ppmwriter.cpp:61-73: header, then "<value> " with a newline after every 19th value
-	std::string s = "P3 " + std::to_string(w) + " " + std::to_string(h) + " 255 \n";
-	size_t n = (size_t) w * h * 3;
-	s.reserve(n * 4 + 64);
-	size_t pos = 1;
-	char buf[8];
-	for (size_t i = 0; i < n; ++i, ++pos) {
-		int len = std::snprintf(buf, sizeof buf, "%d ", (int) rgb8[i]);
-		s.append(buf, (size_t) len);
-		if (pos > 18) {
-			s.push_back('\n');
-			pos = 0;
-		}
-	}
+	const std::string s = ppm_text(rgb8, w, h);
 	bool ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
 	ok = (std::fclose(f) == 0) && ok;
 	return ok ? PTX_OK : fail(PTX_ERR_INVALID, std::string("short write to ") + path);
@@ -1063,6 +1078,260 @@ PtxStatus ptx_write_pfm(const char* path, const float* color, uint32_t w, uint32
 	const uint16_t probe = 1;
 	if (*reinterpret_cast<const uint8_t*>(&probe) != 1) return fail(PTX_ERR_UNSUPPORTED, "big-endian host");
 	return write_blob(path, "PF\n" + std::to_string(w) + " " + std::to_string(h) + "\n-1.0\n", color, (size_t) w * h * 3 * sizeof(float));
+}
+
+// ---------------------------------------------------------------------------
+// image files written beside the rendering
+// ---------------------------------------------------------------------------
+struct PtxWriteJob {
+	std::thread worker;
+	void* pinned = nullptr;
+	hipEvent_t copied = nullptr;
+	int device = 0;
+	PtxStatus status = PTX_OK;
+	std::string error;
+};
+
+PtxStatus ptx_write_image_async(const char* path, PtxImageFormat format, int device, const void* d_pixels, uint32_t w, uint32_t h, void* stream_,
+                                PtxWriteJob** out) {
+	if (!path || !d_pixels || !out) return fail(PTX_ERR_INVALID, "path/d_pixels/job is NULL");
+	*out = nullptr;
+	if (w == 0 || h == 0 || (uint64_t) w * h > 0x7fffffffull / 3) return fail(PTX_ERR_INVALID, "bad image size");
+	if (format != PTX_IMAGE_PPM_ASCII && format != PTX_IMAGE_PPM_BINARY && format != PTX_IMAGE_PFM) return fail(PTX_ERR_INVALID, "unknown image format");
+	HIP_TRY(hipSetDevice(device));
+	const size_t bytes = (size_t) w * h * 3 * (format == PTX_IMAGE_PFM ? sizeof(float) : 1);
+	std::unique_ptr<PtxWriteJob> job(new PtxWriteJob);
+	job->device = device;
+	auto drop = [&]() {
+		if (job->pinned) (void) hipHostFree(job->pinned);
+		if (job->copied) (void) hipEventDestroy(job->copied);
+	};
+	hipError_t e = hipHostMalloc(&job->pinned, bytes, hipHostMallocDefault);
+	if (e != hipSuccess) return fail(PTX_ERR_NOMEM, std::string("pinned host buffer: ") + hipGetErrorString(e));
+	if ((e = hipEventCreateWithFlags(&job->copied, hipEventDisableTiming)) != hipSuccess ||
+	    (e = hipMemcpyAsync(job->pinned, d_pixels, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream_))) != hipSuccess ||
+	    (e = hipEventRecord(job->copied, static_cast<hipStream_t>(stream_))) != hipSuccess) {
+		drop();
+		return fail(PTX_ERR_DEVICE, std::string("device-to-host copy: ") + hipGetErrorString(e));
+	}
+	PtxWriteJob* j = job.get();
+	const std::string file(path);
+	// the worker waits for the copy (not the caller), then formats and writes; the caller's stream is free as soon as
+	// the copy has been queued, and the device buffer may be reused once work queued BEHIND the copy on that stream runs
+	j->worker = std::thread([j, file, format, w, h]() {
+		(void) hipSetDevice(j->device);
+		hipError_t we = hipEventSynchronize(j->copied);
+		if (we != hipSuccess) {
+			j->status = PTX_ERR_DEVICE;
+			j->error = std::string("waiting for the copy: ") + hipGetErrorString(we);
+			return;
+		}
+		PtxStatus st;
+		if (format == PTX_IMAGE_PPM_ASCII) st = ptx_write_ppm(file.c_str(), static_cast<const uint8_t*>(j->pinned), w, h);
+		else if (format == PTX_IMAGE_PPM_BINARY) st = ptx_write_ppm_binary(file.c_str(), static_cast<const uint8_t*>(j->pinned), w, h);
+		else st = ptx_write_pfm(file.c_str(), static_cast<const float*>(j->pinned), w, h);
+		j->status = st;
+		if (st != PTX_OK) j->error = ptx_last_error();  // (this thread's message; handed to the waiting thread below)
+	});
+	*out = job.release();
+	return PTX_OK;
+}
+
+PtxStatus ptx_write_wait(PtxWriteJob* job) {
+	if (!job) return fail(PTX_ERR_INVALID, "job is NULL");
+	if (job->worker.joinable()) job->worker.join();
+	(void) hipSetDevice(job->device);
+	if (job->pinned) (void) hipHostFree(job->pinned);
+	if (job->copied) (void) hipEventDestroy(job->copied);
+	const PtxStatus st = job->status;
+	const std::string msg = job->error;
+	delete job;
+	return st == PTX_OK ? PTX_OK : fail(st, msg);
+}
+
+// ---------------------------------------------------------------------------
+// checkpoints of an accumulation buffer
+// ---------------------------------------------------------------------------
+namespace {
+struct AccumHeader {  // 32 bytes, little endian
+	char magic[8];    // "PTXACC1\0"
+	uint32_t width, height;
+	uint32_t sample_begin, sample_end;  // the samples of every pixel the buffer holds: [begin, end)
+	uint32_t aa_steps;
+	uint32_t reserved;
+};
+const char kAccumMagic[8] = {'P', 'T', 'X', 'A', 'C', 'C', '1', 0};
+}  // namespace
+
+PtxStatus ptx_accum_save(const char* path, int device, const float* d_accum, uint32_t w, uint32_t h, uint32_t aa_steps, uint32_t sample_begin,
+                         uint32_t sample_end, void* stream_) {
+	if (!path || !d_accum) return fail(PTX_ERR_INVALID, "path/d_accum is NULL");
+	if (w == 0 || h == 0 || (uint64_t) w * h > 0x7fffffffull / 3) return fail(PTX_ERR_INVALID, "bad image size");
+	if (sample_begin > sample_end) return fail(PTX_ERR_INVALID, "sample range is inverted");
+	HIP_TRY(hipSetDevice(device));
+	const size_t n = (size_t) w * h * 3;
+	std::vector<float> host(n);
+	HIP_TRY(hipMemcpyAsync(host.data(), d_accum, n * sizeof(float), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream_)));
+	HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
+	AccumHeader hd{};
+	std::memcpy(hd.magic, kAccumMagic, 8);
+	hd.width = w;
+	hd.height = h;
+	hd.sample_begin = sample_begin;
+	hd.sample_end = sample_end;
+	hd.aa_steps = aa_steps;
+	// written under a temporary name and renamed: a checkpoint is either the old one or the new one, never half of one
+	const std::string tmp = std::string(path) + ".part";
+	FILE* f = std::fopen(tmp.c_str(), "wb");
+	if (!f) return fail(PTX_ERR_INVALID, "cannot open " + tmp);
+	bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(host.data(), sizeof(float), n, f) == n;
+	ok = (std::fclose(f) == 0) && ok;
+	if (!ok || std::rename(tmp.c_str(), path) != 0) {
+		std::remove(tmp.c_str());
+		return fail(PTX_ERR_INVALID, std::string("short write to ") + path);
+	}
+	return PTX_OK;
+}
+
+PtxStatus ptx_accum_load(const char* path, int device, float* d_accum, uint32_t w, uint32_t h, uint32_t aa_steps, uint32_t* sample_begin,
+                         uint32_t* sample_end, void* stream_) {
+	if (!path || !d_accum) return fail(PTX_ERR_INVALID, "path/d_accum is NULL");
+	FILE* f = std::fopen(path, "rb");
+	if (!f) return fail(PTX_ERR_INVALID, std::string("cannot open ") + path);
+	AccumHeader hd{};
+	if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, kAccumMagic, 8) != 0) {
+		std::fclose(f);
+		return fail(PTX_ERR_INVALID, std::string(path) + " is not an accumulation checkpoint");
+	}
+	if (hd.width != w || hd.height != h || hd.aa_steps != aa_steps || hd.sample_begin > hd.sample_end) {
+		std::fclose(f);
+		return fail(PTX_ERR_INVALID, std::string(path) + " holds " + std::to_string(hd.width) + "x" + std::to_string(hd.height) + " aa_steps " +
+		                                 std::to_string(hd.aa_steps) + ", not the image asked for");
+	}
+	const size_t n = (size_t) w * h * 3;
+	std::vector<float> host(n);
+	const bool ok = std::fread(host.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
+	std::fclose(f);
+	if (!ok) return fail(PTX_ERR_INVALID, std::string(path) + " is truncated or has trailing bytes");
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipMemcpyAsync(d_accum, host.data(), n * sizeof(float), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream_)));
+	HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
+	if (sample_begin) *sample_begin = hd.sample_begin;
+	if (sample_end) *sample_end = hd.sample_end;
+	return PTX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one image on several GPUs
+// ---------------------------------------------------------------------------
+PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, const PtxRenderParams* rp, float* color, uint8_t* rgb8, double* seconds,
+                                 PtxStats* stats) {
+	if (!scenes || n_scenes < 1) return fail(PTX_ERR_INVALID, "no scenes");
+	for (int i = 0; i < n_scenes; ++i) {
+		if (!scenes[i]) return fail(PTX_ERR_INVALID, "scene " + std::to_string(i) + " is NULL");
+		for (int j = 0; j < i; ++j)
+			if (scenes[j] == scenes[i]) return fail(PTX_ERR_INVALID, "the same scene object twice: every worker needs its own (ptx_scene_create once per GPU)");
+	}
+	PtxStatus st = check_params(rp);
+	if (st != PTX_OK) return st;
+	const auto t0 = std::chrono::steady_clock::now();
+	const size_t n = (size_t) rp->width * rp->height * 3;
+	const uint32_t ns = rp->sample_end - rp->sample_begin;
+	struct Worker {
+		float* d_accum = nullptr;
+		PtxStatus status = PTX_OK;
+		std::string error;
+	};
+	std::vector<Worker> work((size_t) n_scenes);
+	// the reference's fan-out over CPU threads (framework/renderer.cpp:39-53), over GPUs: worker r
+	// renders all pixels for the r-th slice of the per-pixel samples into a buffer on its own GPU
+	auto run = [&](int r) {
+		Worker& w = work[(size_t) r];
+		PtxScene* sc = scenes[r];
+		auto bad = [&](PtxStatus s, std::string m) {
+			w.status = s;
+			w.error = std::move(m);
+		};
+		hipError_t e = hipSetDevice(sc->device);
+		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&w.d_accum), n * sizeof(float));
+		if (e == hipSuccess) e = hipMemsetAsync(w.d_accum, 0, n * sizeof(float), nullptr);
+		if (e != hipSuccess) return bad(PTX_ERR_DEVICE, std::string("worker set-up: ") + hipGetErrorString(e));
+		PtxRenderParams part = *rp;
+		part.sample_begin = rp->sample_begin + (uint32_t) ((uint64_t) ns * (uint64_t) r / (uint64_t) n_scenes);
+		part.sample_end = rp->sample_begin + (uint32_t) ((uint64_t) ns * (uint64_t) (r + 1) / (uint64_t) n_scenes);
+		PtxStats* ps = stats ? stats + r : nullptr;
+		if (ps) std::memset(ps, 0, sizeof *ps);
+		if (part.sample_begin < part.sample_end) {
+			PtxStatus rs = render_accumulate(sc, sc->work, &part, w.d_accum, nullptr, 1, ps, true);
+			if (rs != PTX_OK) return bad(rs, ptx_last_error());
+		}
+		e = hipStreamSynchronize(nullptr);
+		if (e != hipSuccess) bad(PTX_ERR_DEVICE, std::string("worker: ") + hipGetErrorString(e));
+	};
+	{
+		std::vector<std::thread> threads;
+		for (int r = 1; r < n_scenes; ++r) threads.emplace_back(run, r);
+		run(0);
+		for (auto& t : threads) t.join();
+	}
+	auto cleanup = [&]() {
+		for (int r = 0; r < n_scenes; ++r)
+			if (work[(size_t) r].d_accum) {
+				(void) hipSetDevice(scenes[r]->device);
+				(void) hipFree(work[(size_t) r].d_accum);
+			}
+	};
+	for (int r = 0; r < n_scenes; ++r)
+		if (work[(size_t) r].status != PTX_OK) {
+			const PtxStatus ws = work[(size_t) r].status;
+			const std::string msg = "GPU worker " + std::to_string(r) + ": " + work[(size_t) r].error;
+			cleanup();
+			return fail(ws, msg);
+		}
+	// the sum of the buffers on the first scene's GPU: every other GPU's buffer comes over its own
+	// link (xGMI is point to point: the copies of different peers do not share a wire) into a staging
+	// buffer and is added by a kernel; 25 MB per peer at 1920x1080
+	const int dev0 = scenes[0]->device;
+	float* d_stage = nullptr;
+	float* d_color = nullptr;
+	uint8_t* d_rgb = nullptr;
+	auto cleanup0 = [&]() {
+		(void) hipSetDevice(dev0);
+		if (d_stage) (void) hipFree(d_stage);
+		if (d_color) (void) hipFree(d_color);
+		if (d_rgb) (void) hipFree(d_rgb);
+		cleanup();
+	};
+#define TRY_M(expr)                                                                         \
+	do {                                                                                    \
+		hipError_t e_ = (expr);                                                             \
+		if (e_ != hipSuccess) {                                                             \
+			cleanup0();                                                                     \
+			return fail(PTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+		}                                                                                   \
+	} while (0)
+	TRY_M(hipSetDevice(dev0));
+	if (n_scenes > 1) TRY_M(hipMalloc(reinterpret_cast<void**>(&d_stage), n * sizeof(float)));
+	for (int r = 1; r < n_scenes; ++r) {
+		TRY_M(hipMemcpyPeerAsync(d_stage, dev0, work[(size_t) r].d_accum, scenes[r]->device, n * sizeof(float), nullptr));
+		const unsigned grid = (unsigned) std::min<size_t>((n / 4 + kBlock - 1) / kBlock + 1, 4096);
+		hipLaunchKernelGGL(k_add, dim3(grid), dim3(kBlock), 0, nullptr, work[0].d_accum, d_stage, n);
+		TRY_M(hipGetLastError());
+	}
+	TRY_M(hipMalloc(reinterpret_cast<void**>(&d_color), n * sizeof(float)));
+	TRY_M(hipMalloc(reinterpret_cast<void**>(&d_rgb), n));
+	st = ptx_resolve(dev0, work[0].d_accum, rp->width, rp->height, ns ? ns : 1, d_color, d_rgb, nullptr);
+	if (st != PTX_OK) {
+		cleanup0();
+		return st;
+	}
+	if (color) TRY_M(hipMemcpy(color, d_color, n * sizeof(float), hipMemcpyDeviceToHost));
+	if (rgb8) TRY_M(hipMemcpy(rgb8, d_rgb, n, hipMemcpyDeviceToHost));
+	TRY_M(hipDeviceSynchronize());
+#undef TRY_M
+	cleanup0();
+	if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return PTX_OK;
 }
 
 }  // extern "C"

@@ -1670,6 +1670,23 @@ __global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
 	}
 }
 
+// a += b over n floats (the sum of the per-GPU accumulation buffers)
+__global__ __launch_bounds__(kBlock) void k_add(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+	const size_t n4 = n / 4;
+	float4* a4 = reinterpret_cast<float4*>(a);
+	const float4* b4 = reinterpret_cast<const float4*>(b);
+	for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t) gridDim.x * kBlock) {
+		float4 x = a4[i];
+		const float4 y = b4[i];
+		x.x += y.x;
+		x.y += y.y;
+		x.z += y.z;
+		x.w += y.w;
+		a4[i] = x;
+	}
+	for (size_t i = n4 * 4 + (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) a[i] += b[i];
+}
+
 // framework/renderer.cpp:86-89, :286-291 and ppmwriter.cpp:36-43
 __global__ __launch_bounds__(kBlock) void k_resolve(const float* __restrict__ accum, unsigned w, unsigned h, float inv_spp,
                                                     float* __restrict__ color, uint8_t* __restrict__ rgb8) {
