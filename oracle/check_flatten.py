@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE, container-only (needs oracle/_ref/libref.so, i.e. the reference checkout
+at build time).  For every fixture scene: the reference's own load_scene builds its Scene; the
+hand-over of INTEGRATION.md written against the REFERENCE's classes (oracle/ref_flatten.cpp)
+flattens it; the product's host mirror (libpt_host.so: its own loader, octree and flatten)
+flattens the same file.  The two PtxSceneDesc must agree byte for byte: frames (matrices,
+bounds, levels_up), prims in tie-break order (kind, parameters, normal, matrices, material index,
+frame, levels_in), materials, lights, ambient, camera; and the leaf names in the same order.
+Exit code 0 = identical for every scene."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from oracle_lib import Reference, SDF_DIR  # noqa: E402
+
+SCENES = ["cornell.sdf", "example.sdf", "example_fixed.sdf", "cornell_buster.sdf", "superhot_colored.sdf"]
+PARTS = ["frames", "prims", "materials", "lights", "ambient", "camera"]
+
+
+def ref_parts(ref, scene):
+    L = ref.L
+    L.ref_flatten.restype = C.c_void_p
+    L.ref_flatten.argtypes = [C.c_void_p]
+    L.ref_flat_free.argtypes = [C.c_void_p]
+    L.ref_flat_error.restype = C.c_char_p
+    L.ref_flat_error.argtypes = [C.c_void_p]
+    L.ref_flat_array.restype = C.c_void_p
+    L.ref_flat_array.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ref_flat_name.restype = C.c_char_p
+    L.ref_flat_name.argtypes = [C.c_void_p, C.c_int]
+    h = L.ref_flatten(scene)
+    err = L.ref_flat_error(h).decode()
+    if err:
+        raise RuntimeError("reference-side flatten: " + err)
+    out = {}
+    for k, name in enumerate(PARTS):
+        n, eb = C.c_int(0), C.c_int(0)
+        p = L.ref_flat_array(h, k, C.byref(n), C.byref(eb))
+        out[name] = (n.value, C.string_at(p, n.value * eb.value) if n.value else b"")
+    names = [L.ref_flat_name(h, i).decode() for i in range(out["prims"][0])]
+    L.ref_flat_free(h)
+    return out, names
+
+
+def mirror_parts(pt, path):
+    hs = pt.HostScene(path)
+    d = hs.desc.contents
+    out = {
+        "frames": (d.n_frames, C.string_at(d.frames, d.n_frames * C.sizeof(pt.PtxFrame))),
+        "prims": (d.n_prims, C.string_at(d.prims, d.n_prims * C.sizeof(pt.PtxPrim)) if d.n_prims else b""),
+        "materials": (d.n_materials, C.string_at(d.materials, d.n_materials * C.sizeof(pt.PtxMaterial)) if d.n_materials else b""),
+        "lights": (d.n_lights, C.string_at(d.lights, d.n_lights * C.sizeof(pt.PtxLight)) if d.n_lights else b""),
+        "ambient": (3, bytes(memoryview(d.ambient))),
+        "camera": (1, bytes(memoryview(d.camera))),
+    }
+    return out, hs.prim_names()
+
+
+def main():
+    if not Reference.available():
+        print("oracle/_ref/libref.so is absent (no reference checkout at build time): nothing to check")
+        return 2
+    pt = importlib.import_module("path-tracer_amd")
+    ref = Reference()
+    ok = True
+    for name in SCENES:
+        path = f"{SDF_DIR}/{name}"
+        a, an = ref_parts(ref, ref.load(path))
+        b, bn = mirror_parts(pt, path)
+        same = {k: a[k] == b[k] for k in PARTS}
+        same["names"] = an == bn
+        note = ""
+        if not same["prims"] and a["prims"][0] == b["prims"][0]:
+            # example.sdf:25 (`transform blue_sphere2 scale 1.5`) gives Shape::scale two operands the reference
+            # never initialises (scene.cpp:364-371): its matrices hold whatever was on the stack.  The mirror
+            # reads missing operands as NaN.  Such a leaf may differ, in its two matrices only, and only
+            # if the mirror's matrix is not finite (the library drops the leaf; the reference build used
+            # for the goldens never hits it).
+            per = C.sizeof(pt.PtxPrim)
+            x = np.frombuffer(a["prims"][1], np.uint8).reshape(-1, per)
+            y = np.frombuffer(b["prims"][1], np.uint8).reshape(-1, per)
+            rows = np.nonzero((x != y).any(axis=1))[0]
+            mats_at = 16 * 4      # kind, material, frame, levels_in, p[9], normal[3] come first
+            excused = all((x[r, :mats_at] == y[r, :mats_at]).all() and not np.isfinite(np.frombuffer(y[r, mats_at:].tobytes(), np.float32)).all()
+                          for r in rows)
+            if excused:
+                same["prims"] = True
+                note = f"  ({len(rows)} leaf with uninitialised transform operands in the scene file: matrices not compared)"
+        print(f"{name:22s} frames {a['frames'][0]:3d} prims {a['prims'][0]:6d} materials {a['materials'][0]:3d} lights {a['lights'][0]}: " +
+              " ".join(f"{k} {'==' if v else '!='}" for k, v in same.items()) + note)
+        if not all(same.values()):
+            ok = False
+            for k in PARTS:
+                if a[k] != b[k]:
+                    x, y = np.frombuffer(a[k][1], np.uint8), np.frombuffer(b[k][1], np.uint8)
+                    if a[k][0] != b[k][0]:
+                        print(f"   {k}: counts differ, reference {a[k][0]} mirror {b[k][0]}")
+                    else:
+                        bad = np.nonzero(x != y)[0]
+                        per = len(x) // max(a[k][0], 1)
+                        print(f"   {k}: {len(bad)} bytes differ, first in element {bad[0] // per} at byte {bad[0] % per}")
+    print("IDENTICAL" if ok else "DIFFERENT")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -5,6 +5,7 @@
 #include "scene.hpp"
 
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <limits>
 #include <sstream>
@@ -87,14 +88,20 @@ float Triangle::area() const {
 	vec3 c = cross(v1_ - v0_, v2_ - v0_);
 	return std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z) / 2;
 }
-vec3 Triangle::min(mat4 const& transform) const {
+Triangle::Bounds const& Triangle::bounds(mat4 const& transform) const {  // triangle.cpp:25-48
+	Bounds& b = bounds_;
+	if (b.valid && std::memcmp(&b.transform, &transform, sizeof(mat4)) == 0 && std::memcmp(&b.world, &world_transform_, sizeof(mat4)) == 0) return b;
 	mat4 full = transform * world_transform_;
-	return min3(min3(transform_vec(v0_, full), transform_vec(v1_, full)), transform_vec(v2_, full));
+	vec3 a = transform_vec(v0_, full), c = transform_vec(v1_, full), e = transform_vec(v2_, full);
+	b.lo = min3(min3(a, c), e);
+	b.hi = max3(max3(a, c), e);
+	b.transform = transform;
+	b.world = world_transform_;
+	b.valid = true;
+	return b;
 }
-vec3 Triangle::max(mat4 const& transform) const {
-	mat4 full = transform * world_transform_;
-	return max3(max3(transform_vec(v0_, full), transform_vec(v1_, full)), transform_vec(v2_, full));
-}
+vec3 Triangle::min(mat4 const& transform) const { return bounds(transform).lo; }
+vec3 Triangle::max(mat4 const& transform) const { return bounds(transform).hi; }
 
 // ---------------------------------------------------------------- Composite (composite.cpp)
 Composite::Composite(std::string const& name, std::shared_ptr<Material> material) : Shape(name, std::move(material)), bounds_{nullptr} {}

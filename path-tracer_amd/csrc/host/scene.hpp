@@ -165,6 +165,17 @@ public:
 
 private:
 	vec3 v0_, v1_, v2_, n_;
+	// min() / max() of the last (transform, world_transform_) pair asked for: an octree build asks
+	// every triangle for both, under the same matrix, once per octant and level
+	// (composite.cpp:141-147 through box.cpp:73-80), and would otherwise form the same matrix
+	// product and the same three transformed corners over and over.  Same arithmetic, formed once.
+	struct Bounds {
+		mat4 transform, world;
+		vec3 lo, hi;
+		bool valid = false;
+	};
+	mutable Bounds bounds_;
+	Bounds const& bounds(mat4 const& transform) const;
 };
 
 class Composite : public Shape {  // framework/composite.hpp

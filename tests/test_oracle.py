@@ -3,6 +3,8 @@
 Everything here is bit-exact: the oracle restates the reference's fp32 operation order."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -104,3 +106,18 @@ def test_reference_unit_test_cases(port, tmp_path):
     # tests.cpp:33-45 / box.cpp:14-16: min > max throws
     with pytest.raises(ValueError):
         port.prim_intersect(1, [1, 0, 0, 0, 1, 1], [], [[0, 0, 0]], [[0, 0, 1]])
+
+
+def test_reference_side_flatten_equals_the_mirror():
+    """The scene hand-over written against the reference's own classes (oracle/ref_flatten.cpp,
+    compiled with the reference) and the product's host mirror give byte-identical
+    PtxSceneDesc arrays for every fixture scene (oracle/check_flatten.py).  Needs the reference
+    built into oracle/_ref/libref.so, which exists where the reference checkout was present."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    from oracle_lib import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref/libref.so absent")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "oracle", "check_flatten.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
