@@ -149,6 +149,8 @@ void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx
  *   STAGED  three kernels per depth: closest hit -> hit records; shading -> child rays and
  *           shadow-ray records; shadow walk -> accumulate.  Leaner kernels (more waves per
  *           SIMD) at the price of hit records and shadow rays going through HBM.
+ *   DEFAULT staged; fused for calls of fewer than 2^17 samples (previews, tiles), where the
+ *           number of launches decides.
  */
 typedef enum PtxPipeline { PTX_PIPELINE_DEFAULT = 0, PTX_PIPELINE_FUSED = 1, PTX_PIPELINE_STAGED = 2 } PtxPipeline;
 
@@ -188,9 +190,10 @@ int ptx_device_count(void);
 
 /*
  * Validates and uploads a scene to `device`, builds the per-frame BVHs and allocates the
- * ray queues.  queue_bytes = HBM budget for the ray queues (0 = a third of the memory the
- * device has free at this moment, at most 96 GiB; at least 96 MiB is taken; more memory
- * means fewer, larger kernel launches, never different results).
+ * ray queues.  queue_bytes = HBM budget for the ray queues (0 = 8 GiB, or a third of the
+ * memory the device has free at this moment if that is less; at least 96 MiB is taken; more
+ * memory means fewer, larger kernel launches, never different results: 32 GiB is where the
+ * gain ends, worth it for callers that render many images with one scene).
  * Replaces the per-thread Scene copies of framework/renderer.cpp:48.
  * A PtxScene owns its queues and counters: use it from one thread (one render) at a time;
  * different scenes are independent.  ptx_last_error() is per thread.

@@ -529,10 +529,15 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		if (std::isnan(S.root_min[k]) || std::isnan(S.root_max[k])) S.bounds_clean = 0;
 
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
-	if (queue_bytes == 0) {  // a third of what the device has free now, at most 96 GiB (more was measured to add nothing)
+	if (queue_bytes == 0) {
+		// 8 GiB, or a third of what the device has free now if that is less.  Measured on the mesh scene at
+		// 1920x1080, 1024 spp: 8 GiB renders 12 % slower than 32 GiB (more, smaller launches; beyond 32 GiB nothing
+		// is gained), but a block of tens of GiB costs more to map and unmap than it saves on one image
+		// (about 4 ms per GiB to allocate and 23 ms per GiB to free): callers that render many images with
+		// one scene ask for 32 GiB, a one-image caller is better off with the default.
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		queue_bytes = std::min<uint64_t>(free_b / 3, 96ull << 30);
+		queue_bytes = std::min<uint64_t>(free_b / 3, 8ull << 30);
 	}
 	uint64_t cap = queue_bytes / 48;
 	cap = std::min<uint64_t>(cap, 1ull << 33);  // 384 GiB: above any device; each queue is limited on its own (64 sub-queues of at most 2^25 records)
@@ -626,7 +631,9 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	uint64_t launches = 0;
 	const bool prof = sc->profiling > 0 && stats && may_create_events;
 	const bool count_tests = sc->profiling > 1 && stats;
-	const bool staged = rp->pipeline != PTX_PIPELINE_FUSED;  // the default is the staged pipeline (the faster one on the measured scenes)
+	// default: the staged pipeline; below some hundred thousand samples the fused one, whose one launch per depth
+	// instead of three is what counts when a launch holds little work (0.53 against 0.71 ms for 96x64, 4 spp)
+	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED || (rp->pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17));
 	sc->event_tag.clear();
 	// profiling: a pair of events around every launch; tag = kind * kMaxDepthSlots + depth slot
 	auto tick = [&](unsigned kind, unsigned depth, bool begin) -> hipError_t {

@@ -157,7 +157,7 @@ def test_rotated_and_scaled_root_shapes(pt, port, tmp_path):
 def test_full_size_properties_mesh(pt, scenes):
     """BASELINE configs[2] at its full size (cornell + buster_sword, 16 008 triangles, 1920x1080,
     1024 spp, 5 bounces: 2.1 G samples, 9 G rays; the CPU oracle would need hours).  The staged
-    pipeline with the library's default queue memory (13 chunks of primary samples per image, the
+    pipeline with the library's default queue memory (8 GiB: a hundred chunks of primary samples per image, the
     parked mesh walks under full load), the staged pipeline in 2 GiB (hundreds of chunks) and the
     fused pipeline agree to the image bar and count exactly the same rays, shadow rays and hits
     at every depth; the image is the sum of eight ranks' sample ranges."""
