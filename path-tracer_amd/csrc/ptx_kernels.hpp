@@ -832,11 +832,37 @@ __device__ __forceinline__ unsigned long long lanes_below(unsigned lane) { retur
 // consecutive words with ONE atomic instruction (float atomics execute at the memory side,
 // one request per 64-byte line an instruction touches: three instructions of one lane each
 // were three requests per run).  A run of one or two lanes adds the rest from its first lane.
+// Sum over the 64 lanes of a wave, within the rows of 16 by data-parallel-primitive moves (plain
+// vector instructions, no trip through the LDS crossbar), across the four rows by lane reads.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+	return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+	v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+	v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+	v = dpp_add<0x141>(v);  // row_half_mirror
+	v = dpp_add<0x140>(v);  // row_mirror: every lane of a row holds the row's sum
+	const int b = __float_as_int(v);
+	return ((__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+	        __int_as_float(__builtin_amdgcn_readlane(b, 32))) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
+}
+
 __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned pix, f3 v, bool has) {
 	const unsigned long long has_mask = __ballot(has);
 	if (has_mask == 0) return;
 	const unsigned lane = lane_id();
 	if (!has) v = mk(0, 0, 0);
+	{
+		// the usual case at 64 or more samples per pixel: every lane that adds something adds to the
+		// same pixel - one sum over the wave, one atomic instruction
+		const unsigned first_pix = __builtin_amdgcn_readlane(pix, __builtin_ctzll(has_mask));
+		if (__ballot(has && pix != first_pix) == 0) {
+			const float sx = wave_sum(v.x), sy = wave_sum(v.y), sz = wave_sum(v.z);
+			if (lane < 3) atomicAdd(accum + (size_t) first_pix * 3 + lane, lane == 0 ? sx : lane == 1 ? sy : sz);
+			return;
+		}
+	}
 	const unsigned up = __shfl_up(pix, 1);
 	const bool head = lane == 0 || up != pix;
 	const unsigned long long heads = __ballot(head);
