@@ -120,8 +120,9 @@ __device__ __forceinline__ bool box_slab_clean(f3 lo, f3 hi, f3 o, f3 inv, float
 // whether a ray is clean in that sense (per lane)
 __device__ __forceinline__ bool ray_is_clean(f3 o, f3 d, f3 inv) {
 	const float big = 3.0e38f;  // |x| < big: finite (and not NaN)
-	return fabsf(o.x) < big && fabsf(o.y) < big && fabsf(o.z) < big && fabsf(d.x) < big && fabsf(d.y) < big && fabsf(d.z) < big && d.x != 0.0f &&
-	       d.y != 0.0f && d.z != 0.0f && fabsf(inv.x) < big && fabsf(inv.y) < big && fabsf(inv.z) < big;
+	// (a zero component of d has an infinite reciprocal, so it needs no test of its own)
+	return fabsf(o.x) < big && fabsf(o.y) < big && fabsf(o.z) < big && fabsf(d.x) < big && fabsf(d.y) < big && fabsf(d.z) < big &&
+	       fabsf(inv.x) < big && fabsf(inv.y) < big && fabsf(inv.z) < big;
 }
 __device__ __forceinline__ bool box_slab(f3 lo, f3 hi, f3 o, f3 d, float& t) {
 	return box_slab_inv(lo, hi, o, d, mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), t);

@@ -209,6 +209,9 @@ __device__ __forceinline__ float bvh_rcp(float d) {
 	return fabsf(r) > 1e18f ? copysignf(1e18f, r) : r;
 }
 
+// the same clamp applied to a reciprocal already at hand
+__device__ __forceinline__ float finite_rcp(float r) { return fabsf(r) > 1e18f ? copysignf(1e18f, r) : r; }
+
 // far limit for node culling given the best reported distance (reported = raw - kEps)
 __device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0f * kEps + 1e-5f * fabsf(best_t)); }
 
@@ -316,7 +319,7 @@ __device__ __forceinline__ bool box_test(f3 lo, f3 hi, f3 o, f3 d, const RayPre&
 __device__ __forceinline__ RayPre ray_pre(const DevScene& S, f3 o, f3 d) {
 	RayPre r;
 	r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-	r.finv = mk(bvh_rcp(d.x), bvh_rcp(d.y), bvh_rcp(d.z));
+	r.finv = mk(finite_rcp(r.inv.x), finite_rcp(r.inv.y), finite_rcp(r.inv.z));  // from the exact quotient: no second reciprocal
 	r.fnoi = mk(-(o.x * r.finv.x), -(o.y * r.finv.y), -(o.z * r.finv.z));
 	r.clean = S.bounds_clean && __ballot(!ray_is_clean(o, d, r.inv)) == 0;
 	r.dn = mk(0, 0, 0);
