@@ -139,8 +139,9 @@ struct PtxScene {
 	bool bouncing = false;   // some material spawns any child
 	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
 	int profiling = 0;       // 0 off, 1 events around every launch, 2 events + the counting twins of the traversal kernels
-	std::vector<hipEvent_t> events;      // pairs, reused from call to call
-	std::vector<unsigned> event_tag;     // kernel kind and depth of pair k
+	std::vector<hipEvent_t> events;      // reused from call to call
+	std::vector<unsigned> event_tag;     // launch k: kernel kind and depth ...
+	std::vector<unsigned> event_begin;   // ... and the event that marks its begin (its end: the event after that)
 	int n_prims = 0, n_frames = 0, n_nodes = 0, max_depth = 0, grid = 0;
 	uint64_t device_bytes = 0;
 
@@ -635,18 +636,28 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	// instead of three is what counts when a launch holds little work (0.53 against 0.71 ms for 96x64, 4 spp)
 	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED || (rp->pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17));
 	sc->event_tag.clear();
-	// profiling: a pair of events around every launch; tag = kind * kMaxDepthSlots + depth slot
+	sc->event_begin.clear();
+	// profiling: an event after every launch, which is the begin of the next launch as well when that
+	// follows without a host-side wait in between (a stream runs its launches back to back; an event costs
+	// some microseconds of the stream's time, so one per launch instead of two); tag = kind * kMaxDepthSlots + depth slot
+	unsigned n_events = 0;
+	bool chained = false;  // the last event recorded marks the begin of whatever is launched next
 	auto tick = [&](unsigned kind, unsigned depth, bool begin) -> hipError_t {
 		if (!prof) return hipSuccess;
-		size_t k = sc->event_tag.size() * 2 + (begin ? 0 : 1);
-		while (sc->events.size() <= k) {
+		if (begin && chained) return hipSuccess;
+		while (sc->events.size() <= n_events) {
 			hipEvent_t e;
 			hipError_t err = hipEventCreate(&e);
 			if (err != hipSuccess) return err;
 			sc->events.push_back(e);
 		}
-		hipError_t err = hipEventRecord(sc->events[k], stream);
-		if (!begin) sc->event_tag.push_back(kind * kMaxDepthSlots + (depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1));
+		hipError_t err = hipEventRecord(sc->events[n_events], stream);
+		if (!begin) {
+			sc->event_tag.push_back(kind * kMaxDepthSlots + (depth < (unsigned) kMaxDepthSlots ? depth : kMaxDepthSlots - 1));
+			sc->event_begin.push_back(n_events - 1);
+			chained = true;
+		}
+		++n_events;
 		return err;
 	};
 	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * M.max_seg; };
@@ -776,6 +787,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 			if (last) continue;
 			HIP_TRY(hipMemcpyAsync(tails, count_of(d + 1), n_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipStreamSynchronize(stream));
+			chained = false;
 			const unsigned m = fullest(tails);
 			if (m) {
 				PtxStatus st2 = self(self, d + 1, 0, m);
@@ -796,6 +808,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		if (max_depth == 0) continue;
 		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * M.max_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
+		chained = false;
 		unsigned held[kMaxBounces + 2] = {0};
 		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * M.max_seg);
 		for (unsigned d = max_depth; d >= 1; --d) {
@@ -830,7 +843,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 			if (prof)
 				for (size_t k = 0; k < sc->event_tag.size(); ++k) {
 					float ms = 0;
-					HIP_TRY(hipEventElapsedTime(&ms, sc->events[2 * k], sc->events[2 * k + 1]));
+					HIP_TRY(hipEventElapsedTime(&ms, sc->events[sc->event_begin[k]], sc->events[sc->event_begin[k] + 1]));
 					unsigned kind = sc->event_tag[k] / kMaxDepthSlots, slot = sc->event_tag[k] % kMaxDepthSlots;
 					stats->kernel_ms[kind][slot] += ms;
 					stats->kernel_launches[kind][slot] += 1;
