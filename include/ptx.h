@@ -105,6 +105,39 @@ typedef struct PtxPrim {
 	float world_inv[16];
 } PtxPrim;
 
+/*
+ * Octants of the root.  A root with more than 64 children is split by build_octree
+ * (framework/composite.cpp:125-160) into octant Composites, recursively; the children - leaves
+ * and meshes - then sit in octants, some in several, and Composite::intersect (:75-103) only
+ * reaches a child through an octant whose bounds_ box, and that of every octant above it, the ray
+ * enters.  Those boxes come from Shape::min/max, which ignore a sphere's transform
+ * (sphere.cpp:22-28) and use two corners of a box (box.cpp:42-66), so a child can stick out of
+ * the octant it was filed under: what the reference reports then depends on the octants, and a
+ * scene description that is to be answered exactly as the reference does lists them:
+ *   guards       one per octant Composite: its bounds_ box, the octant above it, and the number
+ *                of Composites from it up to the root (both included), which is how often a
+ *                normal found through it is re-normalised (:100)
+ *   occurrences  every child entry met when walking the root's octants depth first, children
+ *                in std::map order - the order Composite::intersect visits them, ties going to
+ *                the first: the octant the entry sits in and the leaf (index into prims) or mesh
+ *                (frame index) it names.  A child of several octants has several occurrences.
+ * With n_guards == 0 (a root of at most 64 children: every scene shipped with the reference)
+ * both lists are ignored.  With guards, every frame-0 leaf and every frame needs at least one
+ * occurrence, and levels_in of frame-0 leaves / levels_up of frames are taken from the guards.
+ */
+typedef struct PtxGuard {
+	float bounds_min[3], bounds_max[3];
+	int32_t parent; /* index of the octant above, -1: a child of the root itself */
+	int32_t levels; /* 2 for an octant of the root, 3 for an octant of such an octant, ... */
+} PtxGuard;
+
+typedef struct PtxOccurrence {
+	int32_t guard; /* index into guards; -1: directly under the root */
+	int32_t prim;  /* a leaf: its index in prims; -1 for a mesh */
+	int32_t frame; /* a mesh: its frame (>= 1); 0 for a leaf */
+	int32_t reserved;
+} PtxOccurrence;
+
 typedef struct PtxSceneDesc {
 	const PtxFrame* frames;
 	int32_t n_frames;
@@ -116,6 +149,10 @@ typedef struct PtxSceneDesc {
 	int32_t n_lights;
 	float ambient[3]; /* Light::intensity of scene.ambient (framework/light.hpp:7-12) */
 	PtxCamera camera;
+	const PtxGuard* guards; /* octants of the root, see above; may be NULL with n_guards == 0 */
+	int32_t n_guards;
+	const PtxOccurrence* occurrences;
+	int32_t n_occurrences;
 } PtxSceneDesc;
 
 typedef struct PtxScene PtxScene; /* opaque: device-resident scene + work queues */
@@ -151,6 +188,8 @@ void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx
  *           SIMD) at the price of hit records and shadow rays going through HBM.
  *   DEFAULT staged; fused for calls of fewer than 2^17 samples (previews, tiles), where the
  *           number of launches decides.
+ * A scene with a split root (PtxSceneDesc::n_guards > 0) always takes the staged kernels, whatever
+ * is asked for: the fused kernel does not know octants.
  */
 typedef enum PtxPipeline { PTX_PIPELINE_DEFAULT = 0, PTX_PIPELINE_FUSED = 1, PTX_PIPELINE_STAGED = 2 } PtxPipeline;
 

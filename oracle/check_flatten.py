@@ -5,7 +5,9 @@ hand-over of INTEGRATION.md written against the REFERENCE's classes (oracle/ref_
 flattens it; the product's host mirror (libpt_host.so: its own loader, octree and flatten)
 flattens the same file.  The two PtxSceneDesc must agree byte for byte: frames (matrices,
 bounds, levels_up), prims in tie-break order (kind, parameters, normal, matrices, material index,
-frame, levels_in), materials, lights, ambient, camera; and the leaf names in the same order.
+frame, levels_in), materials, lights, ambient, camera, the octants of a split root and the child
+entries under them in visiting order (split_root.sdf: 120 shapes and a mesh under the root); and
+the leaf names in the same order.
 Exit code 0 = identical for every scene."""
 import ctypes as C
 import importlib
@@ -19,8 +21,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 from oracle_lib import Reference, SDF_DIR  # noqa: E402
 
-SCENES = ["cornell.sdf", "example.sdf", "example_fixed.sdf", "cornell_buster.sdf", "superhot_colored.sdf"]
-PARTS = ["frames", "prims", "materials", "lights", "ambient", "camera"]
+SCENES = ["cornell.sdf", "example.sdf", "example_fixed.sdf", "cornell_buster.sdf", "superhot_colored.sdf", "split_root.sdf"]
+PARTS = ["frames", "prims", "materials", "lights", "ambient", "camera", "guards", "occurrences"]
 
 
 def ref_parts(ref, scene):
@@ -58,6 +60,8 @@ def mirror_parts(pt, path):
         "lights": (d.n_lights, C.string_at(d.lights, d.n_lights * C.sizeof(pt.PtxLight)) if d.n_lights else b""),
         "ambient": (3, bytes(memoryview(d.ambient))),
         "camera": (1, bytes(memoryview(d.camera))),
+        "guards": (d.n_guards, C.string_at(d.guards, d.n_guards * C.sizeof(pt.PtxGuard)) if d.n_guards else b""),
+        "occurrences": (d.n_occurrences, C.string_at(d.occurrences, d.n_occurrences * C.sizeof(pt.PtxOccurrence)) if d.n_occurrences else b""),
     }
     return out, hs.prim_names()
 
@@ -92,7 +96,7 @@ def main():
             if excused:
                 same["prims"] = True
                 note = f"  ({len(rows)} leaf with uninitialised transform operands in the scene file: matrices not compared)"
-        print(f"{name:22s} frames {a['frames'][0]:3d} prims {a['prims'][0]:6d} materials {a['materials'][0]:3d} lights {a['lights'][0]}: " +
+        print(f"{name:22s} guards {a['guards'][0]:3d} occurrences {a['occurrences'][0]:4d} frames {a['frames'][0]:3d} prims {a['prims'][0]:6d} materials {a['materials'][0]:3d} lights {a['lights'][0]}: " +
               " ".join(f"{k} {'==' if v else '!='}" for k, v in same.items()) + note)
         if not all(same.values()):
             ok = False

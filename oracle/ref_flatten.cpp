@@ -57,6 +57,8 @@ struct Flat {
 	std::vector<PtxPrim> prims;
 	std::vector<PtxMaterial> materials;
 	std::vector<PtxLight> lights;
+	std::vector<PtxGuard> guards;
+	std::vector<PtxOccurrence> occurrences;
 	std::vector<std::string> names;
 	float ambient[3];
 	PtxCamera camera;
@@ -134,24 +136,40 @@ struct Walker {
 		f.parent = parent;
 		f.levels_up = levels_up;
 	}
-	void walk_root(Composite const& c, int levels) {
+	// c: the root (guard -1) or one of its octants (guard = its index in out.guards)
+	void walk_root(Composite const& c, int levels, int guard) {
 		for (auto const& kv : c.children_) {
 			Shape const& s = *kv.second;
 			Composite const* sub = as_composite(s);
 			if (!sub) {
 				emit_leaf(s, 0, levels);
+				out.occurrences.push_back(PtxOccurrence{guard, seen.at(&s), 0, 0});
 				continue;
 			}
 			if (is_identity(sub->world_transform_) && !only_plain_triangles(*sub)) {
-				walk_root(*sub, levels + 1);
+				if (!sub->bounds_) throw std::string("Composite without bounds");
+				PtxGuard g{};
+				glm::vec3 lo = sub->bounds_->min_, hi = sub->bounds_->max_;
+				g.bounds_min[0] = lo.x; g.bounds_min[1] = lo.y; g.bounds_min[2] = lo.z;
+				g.bounds_max[0] = hi.x; g.bounds_max[1] = hi.y; g.bounds_max[2] = hi.z;
+				g.parent = guard;
+				g.levels = levels + 1;
+				int idx = (int) out.guards.size();
+				out.guards.push_back(g);
+				walk_root(*sub, levels + 1, idx);
 				continue;
 			}
-			if (!seen.emplace(&s, -1).second) continue;
+			auto ins = seen.emplace(&s, -(int) out.frames.size());
+			if (!ins.second) {
+				out.occurrences.push_back(PtxOccurrence{guard, -1, -ins.first->second, 0});
+				continue;
+			}
 			if (!sub->bounds_) throw std::string("Composite without bounds");
 			PtxFrame f{};
 			frame_of(*sub, 0, levels, f);
 			int idx = (int) out.frames.size();
 			out.frames.push_back(f);
+			out.occurrences.push_back(PtxOccurrence{guard, -1, idx, 0});
 			walk_mesh(*sub, idx, 0);
 		}
 	}
@@ -173,7 +191,8 @@ void* ref_flatten(void* scene_ptr) {
 		Walker w{*out, {}, {}};
 		w.frame_of(root, -1, 0, f0);
 		out->frames.push_back(f0);
-		w.walk_root(root, 1);
+		w.walk_root(root, 1, -1);
+		if (out->guards.empty()) out->occurrences.clear();
 		for (PointLight const& L : scene->lights) {
 			PtxLight pl{};
 			pl.position[0] = L.position.x; pl.position[1] = L.position.y; pl.position[2] = L.position.z;
@@ -203,6 +222,8 @@ const void* ref_flat_array(void* h, int which, int* count, int* elem_bytes) {
 	case 3: *count = (int) f->lights.size(); *elem_bytes = (int) sizeof(PtxLight); return f->lights.data();
 	case 4: *count = 3; *elem_bytes = 4; return f->ambient;
 	case 5: *count = 1; *elem_bytes = (int) sizeof(PtxCamera); return &f->camera;
+	case 6: *count = (int) f->guards.size(); *elem_bytes = (int) sizeof(PtxGuard); return f->guards.data();
+	case 7: *count = (int) f->occurrences.size(); *elem_bytes = (int) sizeof(PtxOccurrence); return f->occurrences.data();
 	}
 	*count = 0;
 	*elem_bytes = 0;

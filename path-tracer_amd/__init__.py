@@ -64,10 +64,19 @@ class PtxPrim(C.Structure):
                 ("normal", C.c_float * 3), ("world", C.c_float * 16), ("world_inv", C.c_float * 16)]
 
 
+class PtxGuard(C.Structure):
+    _fields_ = [("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("parent", C.c_int32), ("levels", C.c_int32)]
+
+
+class PtxOccurrence(C.Structure):
+    _fields_ = [("guard", C.c_int32), ("prim", C.c_int32), ("frame", C.c_int32), ("reserved", C.c_int32)]
+
+
 class PtxSceneDesc(C.Structure):
     _fields_ = [("frames", C.POINTER(PtxFrame)), ("n_frames", C.c_int32), ("prims", C.POINTER(PtxPrim)), ("n_prims", C.c_int32),
                 ("materials", C.POINTER(PtxMaterial)), ("n_materials", C.c_int32), ("lights", C.POINTER(PtxLight)), ("n_lights", C.c_int32),
-                ("ambient", C.c_float * 3), ("camera", PtxCamera)]
+                ("ambient", C.c_float * 3), ("camera", PtxCamera),
+                ("guards", C.POINTER(PtxGuard)), ("n_guards", C.c_int32), ("occurrences", C.POINTER(PtxOccurrence)), ("n_occurrences", C.c_int32)]
 
 
 class PtxRenderParams(C.Structure):

@@ -109,8 +109,9 @@ struct Walker {
 		}
 	}
 
-	// at root level: c is the root or one of its octants; `levels` Composites from c up to the root, both included
-	void walk_root(Composite const& c, int levels, std::string const& path, int depth) {
+	// at root level: c is the root or one of its octants (`guard`: its index in out.guards, -1 for the root);
+	// `levels` Composites from c up to the root, both included
+	void walk_root(Composite const& c, int levels, std::string const& path, int depth, int guard) {
 		++out.composites;
 		out.max_tree_depth = std::max(out.max_tree_depth, depth);
 		for (auto const& kv : c.children()) {
@@ -118,14 +119,28 @@ struct Walker {
 			if (s.kind() != Shape::Kind::composite) {
 				++out.leaf_entries;
 				emit_leaf(s, 0, levels, path);
+				out.occurrences.push_back(PtxOccurrence{guard, seen.at(&s), 0, 0});
 				continue;
 			}
 			auto const& sub = static_cast<Composite const&>(s);
-			if (is_identity(sub.world_transform()) && !only_plain_triangles(sub)) {
-				walk_root(sub, levels + 1, path + sub.get_name() + "/", depth + 1);  // an octant of the root
+			if (is_identity(sub.world_transform()) && !only_plain_triangles(sub)) {  // an octant of the root
+				if (!sub.bounds()) throw SceneError{"Composite '" + sub.get_name() + "' has no bounds: call build_octree()"};
+				PtxGuard g{};
+				vec3 lo = sub.bounds()->min_corner(), hi = sub.bounds()->max_corner();
+				g.bounds_min[0] = lo.x; g.bounds_min[1] = lo.y; g.bounds_min[2] = lo.z;
+				g.bounds_max[0] = hi.x; g.bounds_max[1] = hi.y; g.bounds_max[2] = hi.z;
+				g.parent = guard;
+				g.levels = levels + 1;
+				int idx = (int) out.guards.size();
+				out.guards.push_back(g);
+				walk_root(sub, levels + 1, path + sub.get_name() + "/", depth + 1, idx);
 				continue;
 			}
-			if (!seen.emplace(&s, -1).second) continue;  // mesh already turned into a frame from an earlier octant
+			auto ins = seen.emplace(&s, -(int) out.frames.size());  // a mesh: remembered by (minus) its frame index
+			if (!ins.second) {  // already turned into a frame from an earlier octant
+				out.occurrences.push_back(PtxOccurrence{guard, -1, -ins.first->second, 0});
+				continue;
+			}
 			if (!sub.bounds()) throw SceneError{"Composite '" + sub.get_name() + "' has no bounds: call build_octree()"};
 			PtxFrame f{};
 			std::memcpy(f.world, sub.world_transform().data(), sizeof f.world);
@@ -137,6 +152,7 @@ struct Walker {
 			f.levels_up = levels;
 			int idx = (int) out.frames.size();
 			out.frames.push_back(f);
+			out.occurrences.push_back(PtxOccurrence{guard, -1, idx, 0});
 			walk_mesh(sub, idx, 0, path + sub.get_name() + "/", depth + 1);
 		}
 	}
@@ -161,7 +177,8 @@ FlatScene flatten_scene(Scene const& scene) {
 	out.frames.push_back(f0);
 
 	Walker w{out, {}, {}};
-	w.walk_root(root, 1, "", 0);
+	w.walk_root(root, 1, "", 0, -1);
+	if (out.guards.empty()) out.occurrences.clear();  // a root that was not split: nothing to list
 
 	for (PointLight const& L : scene.lights) {
 		PtxLight pl{};
@@ -178,6 +195,10 @@ FlatScene flatten_scene(Scene const& scene) {
 	d.n_materials = (int32_t) out.materials.size();
 	d.lights = out.lights.data();
 	d.n_lights = (int32_t) out.lights.size();
+	d.guards = out.guards.empty() ? nullptr : out.guards.data();
+	d.n_guards = (int32_t) out.guards.size();
+	d.occurrences = out.occurrences.empty() ? nullptr : out.occurrences.data();
+	d.n_occurrences = (int32_t) out.occurrences.size();
 	d.ambient[0] = scene.ambient.intensity.r; d.ambient[1] = scene.ambient.intensity.g; d.ambient[2] = scene.ambient.intensity.b;
 	d.camera.fov_x = scene.camera.fov_x;
 	d.camera.position[0] = scene.camera.position.x; d.camera.position[1] = scene.camera.position.y; d.camera.position[2] = scene.camera.position.z;

@@ -16,6 +16,9 @@ struct FlatScene {
 	std::vector<PtxPrim> prims;
 	std::vector<PtxMaterial> materials;
 	std::vector<PtxLight> lights;
+	// octants of the root and the child entries under them in visiting order; both empty when the root was not split
+	std::vector<PtxGuard> guards;
+	std::vector<PtxOccurrence> occurrences;
 	PtxSceneDesc desc{};
 	// per prim: HitPoint::hit_object of the leaf, and its slash-joined path from the root
 	std::vector<std::string> prim_names, prim_paths;

@@ -265,6 +265,27 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		return fail(PTX_ERR_UNSUPPORTED, "frame 0 must be the untransformed root Composite");
 	for (int f = 1; f < D->n_frames; ++f)
 		if (D->frames[f].parent != 0) return fail(PTX_ERR_UNSUPPORTED, "only children of the root may carry a transform (frame.parent must be 0)");
+	// ---- octants of a split root
+	const bool guarded = D->n_guards > 0;
+	if (D->n_guards < 0 || D->n_occurrences < 0 || (guarded && (!D->guards || !D->occurrences)))
+		return fail(PTX_ERR_INVALID, "guards / occurrences: negative count, or NULL array with guards present");
+	if (guarded) {
+		if (D->n_frames >= (1 << kExtraShift)) return fail(PTX_ERR_UNSUPPORTED, "a split root with 2^24 frames or more");
+		for (int g = 0; g < D->n_guards; ++g) {
+			const PtxGuard& G = D->guards[g];
+			if (G.parent < -1 || G.parent >= g) return fail(PTX_ERR_INVALID, "guard " + std::to_string(g) + ": the octant above must come earlier in the list (or be -1)");
+			const int want = G.parent < 0 ? 2 : D->guards[G.parent].levels + 1;
+			if (G.levels != want) return fail(PTX_ERR_INVALID, "guard " + std::to_string(g) + ": levels must be one more than that of the octant above (2 under the root)");
+			if (G.levels - 1 > kMaxExtra) return fail(PTX_ERR_UNSUPPORTED, "guard " + std::to_string(g) + ": octants nested deeper than " + std::to_string(kMaxExtra) + " levels");
+		}
+		for (int k = 0; k < D->n_occurrences; ++k) {
+			const PtxOccurrence& O = D->occurrences[k];
+			const bool leaf = O.prim >= 0 && O.prim < D->n_prims && O.frame == 0 && D->prims[O.prim].frame == 0;
+			const bool mesh = O.prim == -1 && O.frame >= 1 && O.frame < D->n_frames;
+			if (O.guard < -1 || O.guard >= D->n_guards || !(leaf || mesh))
+				return fail(PTX_ERR_INVALID, "occurrence " + std::to_string(k) + ": names no octant, or neither a frame-0 leaf nor a mesh frame");
+		}
+	}
 	int ndev = ptx_device_count();
 	if (ndev <= 0) return fail(PTX_ERR_DEVICE, "no HIP device: this library has no CPU path");
 	if (device < 0 || device >= ndev) return fail(PTX_ERR_INVALID, "device index out of range");
@@ -307,6 +328,32 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	// ---- leaves: frame 0 leaves stay a list; every other frame's triangles go into a BVH.
 	// A leaf or frame whose transform holds a non-finite number can never be hit by the
 	// reference's sphere test and is dropped here for every kind.
+	// split root: the occurrences of every child of the root, grouped per child in visiting order, each with
+	// its tie-break key = its rank in that order (a mesh occurrence takes one key per prim id of the mesh)
+	std::vector<std::vector<int2>> prim_occ(guarded ? D->n_prims : 0), mesh_occ(guarded ? D->n_frames : 0);
+	std::vector<int> frame_id_lo(D->n_frames, INT32_MAX), frame_id_hi(D->n_frames, -1);
+	for (int i = 0; i < D->n_prims; ++i) {
+		const int f = D->prims[i].frame;
+		if (f < 0 || f >= D->n_frames) continue;  // (reported below)
+		frame_id_lo[f] = std::min(frame_id_lo[f], i);
+		frame_id_hi[f] = std::max(frame_id_hi[f], i);
+	}
+	if (guarded) {
+		int64_t key = 0;
+		for (int k = 0; k < D->n_occurrences; ++k) {
+			const PtxOccurrence& O = D->occurrences[k];
+			if (O.prim >= 0) {
+				prim_occ[O.prim].push_back(make_int2(O.guard, (int) key));
+				key += 1;
+			} else {
+				mesh_occ[O.frame].push_back(make_int2(O.guard, (int) key));
+				key += frame_id_hi[O.frame] >= 0 ? frame_id_hi[O.frame] - frame_id_lo[O.frame] + 1 : 0;
+			}
+			if (key > (int64_t) 1 << 30) return fail(PTX_ERR_UNSUPPORTED, "a split root whose occurrences span more than 2^30 tie-break keys");
+		}
+	}
+	std::vector<int2> occ, root_occ;
+	std::vector<int4> frame_occ(D->n_frames, make_int4(0, 0, 0, 0));
 	std::vector<DevRootPrim> root_prims;
 	std::vector<DevRootShade> root_shade;
 	std::vector<float4> root_bound;
@@ -340,12 +387,14 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			f3 n = mk(P.normal[0], P.normal[1], P.normal[2]);
 			if (P.frame > 0) {
 				const PtxFrame& F = D->frames[P.frame];
-				for (int k = 0; k < P.levels_in; ++k) n = normalize(n);
+				for (int k = 0; k < P.levels_in; ++k) n = up_one_level(n);
 				n = normalize(xform_dir(F.world, n));
-				for (int k = 0; k < F.levels_up; ++k) n = normalize(n);
+				// (split root: once for the root here, once more per octant level above the occurrence
+				// of the mesh a ray came through when the hit is shaded)
+				for (int k = 0; k < (guarded ? 1 : F.levels_up); ++k) n = up_one_level(n);
 			} else if (P.kind == PTX_TRIANGLE) {
 				n = xform_dir(P.world, n);
-				for (int k = 0; k < P.levels_in; ++k) n = normalize(n);
+				for (int k = 0; k < (guarded ? 1 : P.levels_in); ++k) n = up_one_level(n);
 			}
 			prim_info[i] = make_float4(n.x, n.y, n.z, pw);
 		}
@@ -380,8 +429,13 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			Q.n[0] = prim_info[i].x;
 			Q.n[1] = prim_info[i].y;
 			Q.n[2] = prim_info[i].z;
-			Q.levels_in = P.levels_in;
+			Q.levels_in = guarded ? 1 : P.levels_in;
 			Q.material = P.material;
+			if (guarded) {
+				if (prim_occ[i].empty()) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": a leaf of a split root without an occurrence");
+				root_occ.push_back(make_int2((int) occ.size(), (int) prim_occ[i].size()));
+				occ.insert(occ.end(), prim_occ[i].begin(), prim_occ[i].end());
+			}
 			root_prims.push_back(R);
 			root_shade.push_back(Q);
 			{
@@ -414,6 +468,11 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		auto const& ids = frame_tris[f];
 		G.has_prims = !ids.empty();
 		if (ids.empty()) continue;
+		if (guarded) {
+			if (mesh_occ[f].empty()) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": a mesh of a split root without an occurrence");
+			frame_occ[f] = make_int4((int) occ.size(), (int) mesh_occ[f].size(), frame_id_lo[f], 0);
+			occ.insert(occ.end(), mesh_occ[f].begin(), mesh_occ[f].end());
+		}
 		std::vector<ptx::Aabb> boxes(ids.size());
 		for (size_t k = 0; k < ids.size(); ++k) {
 			const float* p = D->prims[ids[k]].p;
@@ -463,8 +522,10 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			std::vector<DevRootShade> rs(root_prims.size());
 			std::vector<DevXform> rx(root_prims.size());
 			std::vector<float4> rb(root_bound.size());
+			std::vector<int2> ro(root_occ.size());
 			for (size_t k = 0; k < bvh.order.size(); ++k) {
 				const int32_t from = bvh.order[k];
+				if (guarded) ro[k] = root_occ[from];
 				rp[k] = root_prims[from];
 				rp[k].xform = (int32_t) k;
 				rs[k] = root_shade[from];
@@ -476,6 +537,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			root_shade.swap(rs);
 			xforms.swap(rx);
 			root_bound.swap(rb);
+			root_occ.swap(ro);
 			sc->dev.root_bvh = 1;
 			sc->dev.root_bvh_root = bvh.root_ref;
 			sc->dev.root_node_base = (int32_t) nodes.size() * 4;
@@ -510,6 +572,27 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		if ((st = sc->upload(prim_mats, &S.materials)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	}
 	if ((st = sc->upload(mats, &S.mat_table)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	S.n_guards = 0;
+	if (guarded) {
+		if (root_prims.size() >= (size_t) 1 << kExtraShift) { ptx_scene_destroy(sc.release()); return fail(PTX_ERR_UNSUPPORTED, "a split root with 2^24 leaves or more"); }
+		std::vector<float4> guards((size_t) D->n_guards * 2);
+		for (int g = 0; g < D->n_guards; ++g) {
+			const PtxGuard& G = D->guards[g];
+			float parent_bits, extra_bits;
+			const int32_t extra = G.levels - 1;
+			std::memcpy(&parent_bits, &G.parent, 4);
+			std::memcpy(&extra_bits, &extra, 4);
+			guards[2 * g] = make_float4(G.bounds_min[0], G.bounds_min[1], G.bounds_min[2], parent_bits);
+			guards[2 * g + 1] = make_float4(G.bounds_max[0], G.bounds_max[1], G.bounds_max[2], extra_bits);
+		}
+		if (occ.empty()) occ.push_back(make_int2(-1, 0));
+		if (root_occ.empty()) root_occ.push_back(make_int2(0, 0));
+		if ((st = sc->upload(guards, &S.guards)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+		if ((st = sc->upload(occ, &S.occ)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+		if ((st = sc->upload(root_occ, &S.root_occ)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+		if ((st = sc->upload(frame_occ, &S.frame_occ)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+		S.n_guards = D->n_guards;
+	}
 	if ((st = sc->upload(lights, &S.lights)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	// same addresses; copied as bits because the device pass types the *_k members differently
 	std::memcpy(&S.root_prims_k, &S.root_prims, sizeof(void*));
@@ -528,6 +611,9 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	S.bounds_clean = 1;  // (frame-0 leaves and mesh frames with a non-finite number were dropped above)
 	for (int k = 0; k < 3; ++k)
 		if (std::isnan(S.root_min[k]) || std::isnan(S.root_max[k])) S.bounds_clean = 0;
+	for (int g = 0; g < D->n_guards; ++g)
+		for (int k = 0; k < 3; ++k)
+			if (std::isnan(D->guards[g].bounds_min[k]) || std::isnan(D->guards[g].bounds_max[k])) S.bounds_clean = 0;
 
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
 	if (queue_bytes == 0) {
@@ -634,7 +720,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	const bool count_tests = sc->profiling > 1 && stats;
 	// default: the staged pipeline; below some hundred thousand samples the fused one, whose one launch per depth
 	// instead of three is what counts when a launch holds little work (0.53 against 0.71 ms for 96x64, 4 spp)
-	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED || (rp->pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17));
+	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED || (rp->pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17)) || sc->dev.n_guards != 0;
 	sc->event_tag.clear();
 	sc->event_begin.clear();
 	// profiling: an event after every launch, which is the begin of the next launch as well when that
@@ -665,7 +751,9 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * M.max_seg; };
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
-	const bool rb = sc->dev.root_bvh != 0;  // (the fused kernel has no such variant: it takes the leaves one by one)
+	// the general variant of the traversal kernels: frame-0 leaves under a BVH of their own, or a split root
+	// (the fused kernel has no such variant: it takes the leaves one by one and knows no octants)
+	const bool rb = sc->dev.root_bvh != 0 || sc->dev.n_guards != 0;
 
 	// Sizing (see the note on queues in ptx_kernels.hpp): what a launch takes of segment w of
 	// its input lands in segment w of its outputs, at most `per_ray` records per input ray in
@@ -1008,7 +1096,7 @@ static PtxStatus run_intersect(PtxScene* sc, IntersectArgs& A, int64_t n, int32_
 	A.rdir = static_cast<float*>(d_rd);
 	unsigned grid = (unsigned) std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t) sc->grid);
 	if (grid == 0) grid = 1;
-	hipLaunchKernelGGL(sc->dev.root_bvh ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kBlock), 0, nullptr, A);
+	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kBlock), 0, nullptr, A);
 	TRY_C(hipGetLastError());
 	TRY_C(hipDeviceSynchronize());
 	if (prim) TRY_C(hipMemcpy(prim, d_prim, (size_t) n * 4, hipMemcpyDeviceToHost));

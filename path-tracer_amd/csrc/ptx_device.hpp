@@ -33,6 +33,11 @@ __host__ __device__ __forceinline__ f3 normalize(f3 v) {
 	float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
 	return v * (1.0f / __builtin_sqrtf(sqr));
 }
+// What one Composite with an identity transform (the root, an octant, an OBJ sub-object) does to the normal of a
+// hit it passes up (framework/composite.cpp:100): normalize(transform_vec(n, identity, false)).  With the identity
+// matrix, glm's (m0*x + m1*y) + (m2*z + m3*0) leaves a finite component as it is, except that a negative zero comes
+// out as positive zero - which is exactly what adding +0.0f does.
+__host__ __device__ __forceinline__ f3 up_one_level(f3 n) { return normalize(f3{n.x + 0.0f, n.y + 0.0f, n.z + 0.0f}); }
 __host__ __device__ __forceinline__ bool any_nonzero(f3 a) { return a.x != 0.0f || a.y != 0.0f || a.z != 0.0f; }
 
 // std::min / std::max semantics (b < a ? b : a  /  a < b ? b : a), framework/box.cpp:123-147

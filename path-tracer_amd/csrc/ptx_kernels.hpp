@@ -98,6 +98,14 @@ struct DevScene {
 	int32_t root_bvh;        // != 0: the leaves of frame 0 are many and sit under a BVH of their own (root_walk)
 	int32_t root_bvh_root;   // its root reference
 	int32_t root_node_base;  // first float4 of its nodes in `nodes`
+	// Octants of a split root (more than 64 children, composite.cpp:125-160; n_guards == 0 otherwise).  The
+	// reference reaches a child of the root only through an octant whose bounds, and those of the octants above
+	// it, the ray enters; which occurrence that is also decides ties and how often the normal is re-normalised.
+	int32_t n_guards;
+	const float4* guards;     // 2 float4 per octant: (bounds min, bits(octant above or -1)) (bounds max, bits(levels - 1))
+	const int2* occ;          // occurrences of the root's children, grouped per child in visiting order: (octant or -1, tie-break key)
+	const int2* root_occ;     // per frame-0 leaf slot: (first occurrence, count)
+	const int4* frame_occ;    // per frame: (first occurrence, count, lowest prim id of the frame, -)
 	float ambient[3];
 	float root_min[3], root_max[3];
 };
@@ -124,6 +132,7 @@ struct Hit {
 	int32_t id;     // prim id (index into PtxSceneDesc::prims), -1 = miss
 	int32_t frame;  // 0 = root leaf
 	int32_t slot;   // root leaf: index into root_prims
+	int32_t extra;  // split root only: re-normalisations of the normal beyond the one every root child gets (octant levels)
 };
 
 constexpr int kTestKinds = 5;  // slab tests, triangle tests, sphere tests, box tests, ray transforms
@@ -217,7 +226,7 @@ __device__ __forceinline__ float cull_limit(float best_t) { return best_t + (2.0
 
 template <bool ANY, class TC>
 __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const float4* __restrict__ tris, int bvh_root, int frame, f3 o, f3 d,
-                                         int* __restrict__ stk, Hit& best, float range, TC& tc) {
+                                         int* __restrict__ stk, Hit& best, float range, TC& tc, int id_bias = 0, int extra = 0) {
 	// Reciprocal direction for the node tests only.  A zero (or denormal-small) component
 	// would give inf and then inf - inf = NaN inside the fused slab test, which fminf/fmaxf
 	// would read as "no constraint on the wrong side"; a huge finite reciprocal keeps the
@@ -277,11 +286,12 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 					if (ANY) {
 						if (t <= range) return true;
 					} else {
-						int id = __float_as_int(r2.y);
+						int id = __float_as_int(r2.y) + id_bias;  // (split root: the key of this occurrence of the mesh, see first_reachable)
 						if (t < best.t || (t == best.t && id < best.id)) {
 							best.t = t;
 							best.id = id;
 							best.frame = frame;
+							best.extra = extra;
 							best.slot = first + k;
 							limit = cull_limit(t);
 						}
@@ -384,6 +394,39 @@ __device__ __forceinline__ void frame_ray(const DevScene& S, const DevFrame& F, 
 	}
 }
 
+// Split root: the first occurrence, in the reference's visiting order, of a child of the root (occurrences
+// [first, first + count)) that the ray reaches, i.e. whose octant and every octant above it pass
+// Composite::intersect's bounds test (composite.cpp:78-82; the root's own test is done before).  `key`: the
+// occurrence's rank in visiting order - among equal distances the reference keeps the hit it met first (:93) -
+// and `extra`: the octant levels above the child.  While a ray is traced, Hit::id holds keys (a mesh occurrence
+// owns a run of them, one per triangle in prim order); hit_key_to_id puts the prim id back.
+template <class TC>
+__device__ __forceinline__ bool first_reachable(const DevScene& S, int first, int count, f3 o, f3 d, const RayPre& pre, int& key, int& extra, TC& tc) {
+	for (int k = 0; k < count; ++k) {
+		const int2 oc = S.occ[first + k];
+		int g = oc.x, ex = 0;
+		bool open = true;
+		if (g >= 0) ex = __float_as_int(S.guards[2 * g + 1].w);
+		while (g >= 0 && open) {
+			const float4 lo = S.guards[2 * g], hi = S.guards[2 * g + 1];
+			float unused;
+			tc.slab();
+			open = box_test(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), o, d, pre, unused);
+			g = __float_as_int(lo.w);
+		}
+		if (open) {
+			key = oc.y;
+			extra = ex;
+			return true;
+		}
+	}
+	return false;
+}
+__device__ __forceinline__ void hit_key_to_id(const DevScene& S, Hit& h) {
+	if (!S.n_guards || h.id < 0) return;
+	h.id = h.frame == 0 ? S.root_prims[h.slot].id : __float_as_int(S.tris[(size_t) S.frames[h.frame].tri_base + (size_t) h.slot * 3 + 2].y);
+}
+
 // The same test with the leaf chosen per lane (ordinary loads instead of scalar ones): the
 // leaves of a large frame 0 are reached through a BVH, and lanes arrive at different ones.
 template <class TC>
@@ -457,12 +500,19 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 				float t;
 				int id;
 				if (root_prim_t_lane(S, first + k, o, d, pre, t, id, tc)) {
+					int extra = 0;
+					if (S.n_guards) {  // split root: only through an octant the ray enters
+						if (ANY ? !(t <= range) : !(t <= best.t)) continue;
+						const int2 ro = S.root_occ[first + k];
+						if (!first_reachable(S, ro.x, ro.y, o, d, pre, id, extra, tc)) continue;
+					}
 					if (ANY) {
 						if (t <= range) return true;
 					} else if (t < best.t || (t == best.t && id < best.id)) {
 						best.t = t;
 						best.id = id;
 						best.frame = 0;
+						best.extra = extra;
 						best.slot = first + k;
 						limit = cull_limit(t);
 					}
@@ -494,6 +544,7 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	best.id = -1;
 	best.frame = 0;
 	best.slot = 0;
+	best.extra = 0;
 	float unused;
 	tc.slab();
 	if (!box_test(ld3(S.root_min), ld3(S.root_max), o, d, pre, unused)) return false;
@@ -506,11 +557,19 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, cull_limit(best.t)))) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
 		float t;
-		const bool hit = root_prim_t(S, P, o, d, pre, t, tc);
-		const bool better = hit && (t < best.t || (t == best.t && P.id < best.id));
+		bool hit = root_prim_t(S, P, o, d, pre, t, tc);
+		int key = P.id, extra = 0;
+		if (RB && S.n_guards) {  // split root: only through an octant the ray enters
+			if (hit && t <= best.t) {
+				const int2 ro = S.root_occ[i];
+				hit = first_reachable(S, ro.x, ro.y, o, d, pre, key, extra, tc);
+			}
+		}
+		const bool better = hit && (t < best.t || (t == best.t && key < best.id));
 		best.t = better ? t : best.t;
-		best.id = better ? P.id : best.id;
+		best.id = better ? key : best.id;
 		best.slot = better ? i : best.slot;
+		if (RB) best.extra = better ? extra : best.extra;
 	}
 	return true;
 }
@@ -527,7 +586,7 @@ __device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, co
 	}
 	return mask;
 }
-template <bool KNOWN, class TC>
+template <bool KNOWN, bool RB, class TC>
 __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, const RayPre& pre, unsigned known, int* __restrict__ stk, Hit& best, TC& tc) {
 	float unused;
 	for (int f = 1; f < S.n_frames; ++f) {
@@ -539,9 +598,16 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 			tc.slab();
 			if (!box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, unused)) continue;
 		}
+		int bias = 0, extra = 0;
+		if (RB && S.n_guards) {  // split root: the mesh only through an octant the ray enters
+			const int4 fo = S.frame_occ[f];
+			int key;
+			if (!first_reachable(S, fo.x, fo.y, o, d, pre, key, extra, tc)) continue;
+			bias = key - fo.z;
+		}
 		f3 lo, ld;
 		frame_ray(S, F, f, o, d, lo, ld, tc);
-		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc);
+		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, bias, extra);
 	}
 }
 template <bool RB = false>
@@ -549,7 +615,8 @@ __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int
 	const RayPre pre = ray_pre(S, o, d);
 	NoCount tc;
 	if (!closest_root<RB>(S, o, d, pre, stk, best, tc)) return;
-	closest_frames<false>(S, o, d, pre, 0u, stk, best, tc);
+	closest_frames<false, RB>(S, o, d, pre, 0u, stk, best, tc);
+	if (RB) hit_key_to_id(S, best);
 }
 
 // find_light_block(...).does_intersect, framework/renderer.cpp:168-175: the closest hit
@@ -569,7 +636,14 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 			tc.slab();
 			if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, limit))) continue;
 			const DevRootPrim P = kload(S.root_prims_k + i);
-			if (root_prim_t(S, P, o, d, pre, t, tc) && t <= range) return true;
+			if (root_prim_t(S, P, o, d, pre, t, tc) && t <= range) {
+				if (RB && S.n_guards) {
+					const int2 ro = S.root_occ[i];
+					int key, extra;
+					if (!first_reachable(S, ro.x, ro.y, o, d, pre, key, extra, tc)) continue;
+				}
+				return true;
+			}
 		}
 	}
 	for (int f = 1; f < S.n_frames; ++f) {
@@ -577,6 +651,11 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 		if (!F.has_prims) continue;
 		tc.slab();
 		if (!box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, t)) continue;
+		if (RB && S.n_guards) {
+			const int4 fo = S.frame_occ[f];
+			int key, extra;
+			if (!first_reachable(S, fo.x, fo.y, o, d, pre, key, extra, tc)) continue;
+		}
 		f3 lo, ld;
 		frame_ray(S, F, f, o, d, lo, ld, tc);
 		if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range, tc)) return true;
@@ -632,7 +711,7 @@ __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, 
 				s.pos = o + d * h.t;
 			}
 			s.rdir = d;
-			for (int k = 0; k < Q.levels_in; ++k) s.n = normalize(s.n);  // identity-transform Composites up to the root
+			for (int k = 0; k < Q.levels_in; ++k) s.n = up_one_level(s.n);  // identity-transform Composites up to the root
 		}
 	} else {
 		const float* Fwinv = T.fwinv[h.frame].m;  // h.frame differs between lanes: per-lane reads
@@ -647,7 +726,9 @@ __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, 
 __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
 	float4 info = make_float4(0.f, 0.f, 0.f, 0.f);
 	if (h.frame != 0) info = S.prim_info[h.id];
-	return surface_of(device_tables(S), o, d, h, info);
+	Surface s = surface_of(device_tables(S), o, d, h, info);
+	for (int k = 0; k < h.extra; ++k) s.n = up_one_level(s.n);  // octants of a split root above the child (composite.cpp:100)
+	return s;
 }
 
 struct Material {
@@ -1146,6 +1227,14 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 // on (kWalkNow lanes) the wave parks those rays - their slot in the queue and the best hit so
 // far - in a small ring in LDS and walks once 64 of them have gathered, with every lane busy
 // at the start.
+// `where` of a hit record: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame); with a split
+// root the octant levels above the child ride in the bits from kExtraShift up (0 otherwise: the plain numbers)
+constexpr int kExtraShift = 24;
+constexpr int kMaxExtra = 63;
+__device__ __forceinline__ int hit_where(const Hit& h) {
+	const int v = (h.frame == 0 ? h.slot : h.frame) | (h.extra << kExtraShift);
+	return h.frame == 0 ? v : -v;
+}
 constexpr unsigned kRing = 128;    // parked rays per wave
 constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
 template <bool PRIMARY, bool RB, class TC>
@@ -1168,9 +1257,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		const unsigned long long m = __ballot(hit);
 		if (!m) return;
 		const unsigned my = n_hit + __builtin_popcountll(m & lanes_below(lane));
-		// where: root leaf = its slot in root_prims (>= 0), mesh triangle = -(frame)
-		const int where = h.frame == 0 ? h.slot : -h.frame;
-		if (hit && my < A.seg_cap) my_hits[my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(where), __uint_as_float(ref));
+		if (hit && my < A.seg_cap) my_hits[my] = make_float4(h.t, __int_as_float(h.id), __int_as_float(hit_where(h)), __uint_as_float(ref));
 		n_hit += __builtin_popcountll(m);  // (never beyond seg_cap: a ray leaves at most one hit)
 	};
 	// the mesh walks of the `count` most recently parked rays
@@ -1179,6 +1266,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		h.id = -1;
 		h.frame = 0;
 		h.slot = 0;
+		h.extra = 0;
 		h.t = kInf;
 		unsigned ref = 0;
 		if (lane < count) {
@@ -1186,12 +1274,17 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			h.t = rq->x;
 			h.id = __float_as_int(rq->y);
 			h.slot = __float_as_int(rq->z);
+			if (RB) {
+				h.extra = h.slot >> kExtraShift;
+				h.slot &= (1 << kExtraShift) - 1;
+			}
 			ref = __float_as_uint(rq->w);
 			f3 o, d, w;
 			unsigned pix;
 			input_ray<PRIMARY>(A, ref, o, d, w, pix);
 			const RayPre pre = ray_pre(A.S, o, d);
-			closest_frames<false>(A.S, o, d, pre, 0u, stk, h, tc);
+			closest_frames<false, RB>(A.S, o, d, pre, 0u, stk, h, tc);
+			if (RB) hit_key_to_id(A.S, h);
 		}
 		parked -= count;
 		emit(h.id >= 0, h, ref);
@@ -1220,6 +1313,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		h.id = -1;
 		h.frame = 0;
 		h.slot = 0;
+		h.extra = 0;
 		h.t = kInf;
 		f3 o = {0, 0, 0}, d = {0, 0, 1}, w;
 		unsigned pix, frames = 0;
@@ -1248,9 +1342,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 		// walk here, the rays are in registers
 		const bool walk_now = PRIMARY || np >= kWalkNow;
 		if (walk_now) {
-			if (park) closest_frames<true>(A.S, o, d, pre, frames, stk, h, tc);
+			if (park) closest_frames<true, RB>(A.S, o, d, pre, frames, stk, h, tc);
 			park = false;
 		}
+		if (RB && !park) hit_key_to_id(A.S, h);  // (a parked ray keeps its key until its mesh walks are done)
 		if (PRIMARY) {
 			emit(h.id >= 0 && !park, h, ref);
 		} else {  // the step's own hits: placed now, stored at the top of the next step
@@ -1258,7 +1353,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 			const unsigned long long hm = __ballot(hit);
 			pend = hit;
 			pend_at = n_hit + __builtin_popcountll(hm & lanes_below(lane));
-			pend_rec = make_float4(h.t, __int_as_float(h.id), __int_as_float(h.frame == 0 ? h.slot : -h.frame), __uint_as_float(ref));
+			pend_rec = make_float4(h.t, __int_as_float(h.id), __int_as_float(hit_where(h)), __uint_as_float(ref));
 			n_hit += __builtin_popcountll(hm);
 		}
 		if (np && !walk_now) {
@@ -1267,7 +1362,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
 				volatile float4* rq = ring + (parked + __builtin_popcountll(m & lanes_below(lane)));
 				rq->x = h.t;
 				rq->y = __int_as_float(h.id);
-				rq->z = __int_as_float(h.slot);
+				rq->z = __int_as_float(RB ? (h.slot | (h.extra << kExtraShift)) : h.slot);
 				rq->w = __uint_as_float(ref);
 			}
 			parked += np;
@@ -1462,7 +1557,13 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? 4 : 3) void k_shade(B
 			Hit h;
 			h.t = hr.x;
 			h.id = __float_as_int(hr.y);
-			const int where = __float_as_int(hr.z);
+			int where = __float_as_int(hr.z);
+			h.extra = 0;
+			if (A.S.n_guards) {  // split root: octant levels in the high bits
+				const int v = where < 0 ? -where : where;
+				h.extra = v >> kExtraShift;
+				where = where < 0 ? -(v & ((1 << kExtraShift) - 1)) : (v & ((1 << kExtraShift) - 1));
+			}
 			h.frame = where < 0 ? -where : 0;
 			h.slot = where < 0 ? 0 : where;
 			if (PRIMARY) {
@@ -1474,6 +1575,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? 4 : 3) void k_shade(B
 				pix = __float_as_uint(ray.c.y);
 			}
 			sf = surface_of(T, o, d, h, info);
+			for (int k = 0; k < h.extra; ++k) sf.n = up_one_level(sf.n);  // octants of a split root above the child (composite.cpp:100)
 			const Material M = material_of(T, h, info);
 			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
 			kd = M.kd;

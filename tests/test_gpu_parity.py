@@ -440,12 +440,11 @@ def test_many_root_shapes(pt, port, tmp_path):
     """A frame 0 with hundreds of shapes of all three kinds (some glass, some mirrors; the
     triangles rotated, scaled, translated): past 16 leaves the library walks a BVH of their
     bounding boxes instead of the list; hits stay bit-identical to the reference, images within
-    the bar, in both pipelines (the fused one keeps the list).
-    Spheres and boxes stay untransformed here on purpose: with more than 64 children the
-    reference's root sorts them into octants by bounds that ignore a sphere's transform and take
-    two corners of a box (composite.cpp:120-161, sphere.cpp, box.cpp:42-66), and then loses a
-    moved sphere or box whose octant the ray does not cross; this library finds such a shape
-    where it really is (a documented deviation, no shipped scene has that many root shapes)."""
+    the bar, whichever pipeline is asked for.  With more than 64 children the reference's root is
+    split into octants (composite.cpp:120-161); the description lists them and the library answers
+    through them (a split root always takes the staged kernels).  Spheres and boxes stay
+    untransformed here, so that every shape lies inside its octants;
+    test_split_root_is_answered_through_its_octants (test_gpu_shapes.py) moves them."""
     rng = np.random.default_rng(5)
     lines = ["define material a 1 0 0 1 0 0 1 1 1 20 0 1 1", "define material b 0 1 0 0 1 0 1 1 1 8 0.4 1 1.3",
              "define material c 0 0 1 0 0 1 1 1 1 50 0.1 0.3 1.5", "define material d .8 .8 .8 .8 .8 .8 0 0 0 0 0 1 1"]

@@ -34,6 +34,38 @@ def test_flatten_matches_oracle_scene_data(pt, port, scenes):
     assert d.n_frames == 2 and d.frames[1].parent == 0 and d.frames[1].levels_up == 1
 
 
+def test_split_root_lists_its_octants(pt, port):
+    """A root of more than 64 children (fixtures/sdf/split_root.sdf: 120 shapes and a mesh): the
+    description carries one guard per octant Composite, parents before children, levels counting
+    up from 2, and one occurrence per child entry in visiting order - every frame-0 leaf and the
+    mesh at least once, shapes that straddle octants several times; the leaves' first occurrences
+    come in prim order (the tie-break order).  Scenes whose root is not split carry neither."""
+    hs = pt.HostScene(pt.SDF_DIR + "/split_root.sdf")
+    d = hs.desc.contents
+    assert d.n_guards >= 8 and d.n_frames == 2
+    for g in range(d.n_guards):
+        G = d.guards[g]
+        assert -1 <= G.parent < g
+        assert G.levels == (2 if G.parent < 0 else d.guards[G.parent].levels + 1)
+        assert all(G.bounds_min[k] <= G.bounds_max[k] for k in range(3))
+    occ = [(d.occurrences[k].guard, d.occurrences[k].prim, d.occurrences[k].frame) for k in range(d.n_occurrences)]
+    assert all(-1 <= g < d.n_guards and ((p >= 0 and f == 0) or (p == -1 and f == 1)) for g, p, f in occ)
+    leaves = [i for i in range(d.n_prims) if d.prims[i].frame == 0]
+    assert len(leaves) == 120
+    firsts = []
+    for g, p, f in occ:
+        if p >= 0 and p not in firsts:
+            firsts.append(p)
+    assert firsts == leaves
+    assert sum(1 for g, p, f in occ if f == 1) >= 2            # the mesh lies in several octants
+    assert len(occ) > 121
+    # the oracle's tree has the same number of composites above the leaves (root + octants + mesh parts)
+    assert hs.tree_stats()["composites"] >= 1 + d.n_guards
+    for name in ("cornell.sdf", "example.sdf"):
+        e = pt.HostScene(pt.SDF_DIR + "/" + name).desc.contents
+        assert e.n_guards == 0 and e.n_occurrences == 0
+
+
 def test_octree_statistics_of_the_mesh_scenes(pt, scenes):
     """Octree shape of the reference build: buster_sword 16 008 faces -> 790 composites,
     36 927 leaf entries; colored-buster keeps 15 959 of its 16 008 faces (octant rounding
