@@ -1237,8 +1237,11 @@ __device__ __forceinline__ int hit_where(const Hit& h) {
 }
 constexpr unsigned kRing = 128;    // parked rays per wave
 constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
+#ifndef PTX_PRIMARY_WAVES
+#define PTX_PRIMARY_WAVES 5
+#endif
 template <bool PRIMARY, bool RB, class TC>
-__global__ __launch_bounds__(kBlock) void k_trace(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
 	int* stk = lds_stack + threadIdx.x;
@@ -1667,7 +1670,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? 4 : 3) void k_shade(B
 // unblocked ray adds its contribution to its pixel
 template <bool RB, class TC>
 #ifndef PTX_SHADOW_WAVES
-#define PTX_SHADOW_WAVES 4
+#define PTX_SHADOW_WAVES 5
 #endif
 __global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A) {
 	__shared__ int lds_stack[kStack * kBlock];
