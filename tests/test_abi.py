@@ -36,7 +36,7 @@ def test_struct_sizes_match_the_header(pt, tmp_path):
     """The ctypes mirrors have the sizes a C compiler gives the structs of include/ptx.h (the
     header is compiled as plain C here, which also shows that it is one)."""
     import subprocess
-    names = ["PtxMaterial", "PtxLight", "PtxCamera", "PtxFrame", "PtxPrim", "PtxSceneDesc", "PtxRenderParams", "PtxStats"]
+    names = ["PtxMaterial", "PtxLight", "PtxCamera", "PtxFrame", "PtxPrim", "PtxGuard", "PtxOccurrence", "PtxSceneDesc", "PtxRenderParams", "PtxStats"]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "ptx.h"\nint main(void) {\n' +
                    "".join(f'printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "return 0; }\n")
@@ -63,3 +63,40 @@ def test_bad_arguments_are_rejected_without_a_device(pt):
     assert b"NULL" in L.ptx_last_error()
     assert L.ptx_write_ppm(None, None, 1, 1) == 1
     assert L.ptx_scene_set_profiling(None, 1) == 1
+
+
+def test_malformed_octant_lists_are_rejected_without_a_device(pt):
+    """The octant lists of a split root (PtxGuard / PtxOccurrence) are checked before anything
+    touches a device: an octant must come after the octant above it, its level count must follow
+    from that one, and an occurrence must name an existing octant and a frame-0 leaf or a mesh."""
+    L = pt.ptx_lib()
+    hs = pt.HostScene(pt.SDF_DIR + "/split_root.sdf")
+    good = hs.desc.contents
+    assert good.n_guards > 0
+
+    def attempt(change):
+        guards = (pt.PtxGuard * good.n_guards)(*[good.guards[i] for i in range(good.n_guards)])
+        occ = (pt.PtxOccurrence * good.n_occurrences)(*[good.occurrences[i] for i in range(good.n_occurrences)])
+        d = type(good).from_buffer_copy(good)
+        d.guards, d.occurrences = guards, occ
+        change(d, guards, occ)
+        out = ctypes.c_void_p()
+        st = L.ptx_scene_create(ctypes.byref(d), 0, 0, ctypes.byref(out))
+        return st, L.ptx_last_error().decode()
+
+    def parent_after(d, g, o):
+        g[0].parent = 3
+    def wrong_levels(d, g, o):
+        g[1].levels += 1
+    def no_such_octant(d, g, o):
+        o[5].guard = d.n_guards
+    def neither_leaf_nor_mesh(d, g, o):
+        o[2].prim, o[2].frame = -1, 0
+    def missing_list(d, g, o):
+        d.occurrences = None
+    for change, word in ((parent_after, "guard 0"), (wrong_levels, "guard 1"), (no_such_octant, "occurrence 5"), (neither_leaf_nor_mesh, "occurrence 2"),
+                         (missing_list, "NULL")):
+        st, msg = attempt(change)
+        assert st == 1 and word in msg, (change.__name__, st, msg)
+    st, msg = attempt(lambda d, g, o: None)           # the untouched description gets as far as the device
+    assert st == (0 if pt.device_count() > 0 else 3), msg
