@@ -193,6 +193,16 @@ void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx
  */
 typedef enum PtxPipeline { PTX_PIPELINE_DEFAULT = 0, PTX_PIPELINE_FUSED = 1, PTX_PIPELINE_STAGED = 2 } PtxPipeline;
 
+/*
+ * Flag, OR-ed into PtxRenderParams::pipeline.  A reflected or refracted ray whose weight - the product of the
+ * factors the reference will multiply its colour by on the way up (renderer.cpp:120-133, :194-225) - is exactly
+ * zero in all three channels cannot change the pixel, and by default is not traced.  The reference traces it
+ * and multiplies the result by that zero; the two differ only if the result is not finite (0 * NaN = NaN: a box
+ * hit that matches no face reports a NaN normal, box.cpp:167-182).  With this flag every child is traced, and
+ * the ray counts equal the reference's as well.
+ */
+#define PTX_TRACE_ZERO_WEIGHT 0x100u
+
 /* Work done by the last ptx_render_accumulate on this scene (whole call). */
 typedef struct PtxStats {
 	uint64_t samples;      /* primary rays                                           */

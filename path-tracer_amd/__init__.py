@@ -253,10 +253,15 @@ def _ptr(a):
 PIPELINES = {"default": 0, "fused": 1, "staged": 2}
 
 
-def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0):
+TRACE_ZERO_WEIGHT = 0x100
+
+
+def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0, zero_weight=False):
+    """zero_weight: also trace child rays of exactly zero weight, as the reference does (PTX_TRACE_ZERO_WEIGHT)"""
     if sample_end is None:
         sample_end = aa_steps * aa_steps
-    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end, PIPELINES[pipeline], jitter_seed)
+    return PtxRenderParams(width, height, aa_steps, max_ray_bounces, sample_begin, sample_end,
+                           PIPELINES[pipeline] | (TRACE_ZERO_WEIGHT if zero_weight else 0), jitter_seed)
 
 
 class HostScene:
@@ -365,8 +370,8 @@ class DeviceScene:
         _check(self.L.ptx_scene_info(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
         return dict(n_frames=a.value, n_prims=b.value, n_bvh_nodes=c.value, max_bvh_depth=d.value, device_bytes=e.value)
 
-    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0):
-        rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline, jitter_seed)
+    def render_image(self, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0, zero_weight=False):
+        rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline, jitter_seed, zero_weight)
         color = np.zeros((h, w, 3), np.float32)
         rgb = np.zeros((h, w, 3), np.uint8)
         sec = C.c_double(0)

@@ -161,6 +161,16 @@ struct PtxScene {
 
 namespace {
 
+// The root hands every ray on through its world_transform_inv_, the computed inverse of the identity
+// (composite.cpp:83, shape.cpp:3-7), which leaves a position as it is except that a negative zero may turn
+// positive.  For primary rays the origin is the camera position: mapped here, once.
+void root_sees_camera(const DevScene& S, DevCamera& cam) {
+	const f3 p = xform_point(S.root_winv, mk(cam.m[12], cam.m[13], cam.m[14]));
+	cam.m[12] = p.x;
+	cam.m[13] = p.y;
+	cam.m[14] = p.z;
+}
+
 void camera_basis(const PtxCamera& c, const PtxRenderParams& rp, DevCamera& out) {
 	// framework/renderer.cpp:27-37.  tan is the double overload there; the quotient is
 	// formed in double and rounded once.
@@ -236,7 +246,7 @@ PtxStatus check_params(const PtxRenderParams* p) {
 	if (p->sample_begin > p->sample_end || p->sample_end > p->aa_steps * p->aa_steps)
 		return fail(PTX_ERR_INVALID, "sample range outside [0, aa_steps^2]");
 	if (p->max_ray_bounces > kMaxBounces) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must not exceed 63");
-	if (p->pipeline > PTX_PIPELINE_STAGED) return fail(PTX_ERR_INVALID, "unknown pipeline");
+	if ((p->pipeline & ~(uint32_t) PTX_TRACE_ZERO_WEIGHT) > PTX_PIPELINE_STAGED) return fail(PTX_ERR_INVALID, "unknown pipeline");
 	return PTX_OK;
 }
 
@@ -608,6 +618,44 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(S.ambient, D->ambient, sizeof S.ambient);
 	std::memcpy(S.root_min, D->frames[0].bounds_min, sizeof S.root_min);
 	std::memcpy(S.root_max, D->frames[0].bounds_max, sizeof S.root_max);
+	// the answer to a ray with a NaN direction (nan_ray_hit): the first leaf in visiting order (= prim order) that
+	// is not a sphere and was kept; a box is "hit" at infinity, a triangle at distance NaN
+	S.nan_id = -1;
+	S.nan_frame = S.nan_slot = S.nan_extra = 0;
+	S.nan_t = 0.0f;
+	for (int i = 0; i < D->n_prims && S.nan_id < 0; ++i) {
+		const PtxPrim& P = D->prims[i];
+		if (P.kind == PTX_SPHERE) continue;
+		if (P.frame == 0) {
+			for (size_t k = 0; k < root_prims.size(); ++k)
+				if (root_prims[k].id == i) {
+					S.nan_id = i;
+					S.nan_slot = (int32_t) k;
+					if (guarded) S.nan_extra = prim_occ[i].front().x >= 0 ? D->guards[prim_occ[i].front().x].levels - 1 : 0;
+				}
+		} else if (frames[P.frame].has_prims) {
+			const DevFrame& G = frames[P.frame];
+			const size_t n_tri = frame_tris[P.frame].size();
+			for (size_t k = 0; k < n_tri; ++k) {
+				int32_t id;
+				std::memcpy(&id, &tris[(size_t) G.tri_base + 3 * k + 2].y, 4);
+				if (id == i) {
+					S.nan_id = i;
+					S.nan_frame = P.frame;
+					S.nan_slot = (int32_t) k;
+					if (guarded) S.nan_extra = mesh_occ[P.frame].front().x >= 0 ? D->guards[mesh_occ[P.frame].front().x].levels - 1 : 0;
+				}
+			}
+		}
+		if (S.nan_id >= 0) S.nan_t = P.kind == PTX_BOX ? std::numeric_limits<float>::infinity() : std::numeric_limits<float>::quiet_NaN();
+	}
+	std::memcpy(S.root_winv, D->frames[0].world_inv, sizeof S.root_winv);
+	std::memcpy(S.leaf_winv, D->frames[0].world_inv, sizeof S.leaf_winv);
+	for (int i = 0; i < D->n_prims; ++i)
+		if (D->prims[i].frame > 0) {  // an untransformed mesh triangle's own inverse (the same bits for all of them)
+			std::memcpy(S.leaf_winv, D->prims[i].world_inv, sizeof S.leaf_winv);
+			break;
+		}
 	S.bounds_clean = 1;  // (frame-0 leaves and mesh frames with a non-finite number were dropped above)
 	for (int k = 0; k < 3; ++k)
 		if (std::isnan(S.root_min[k]) || std::isnan(S.root_max[k])) S.bounds_clean = 0;
@@ -703,6 +751,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	BounceArgs A{};
 	A.S = sc->dev;
 	camera_basis(sc->camera, *rp, A.cam);
+	root_sees_camera(sc->dev, A.cam);
 	A.accum = d_accum;
 	A.counters = M.counters;
 	A.stat = M.stat;
@@ -720,7 +769,9 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	const bool count_tests = sc->profiling > 1 && stats;
 	// default: the staged pipeline; below some hundred thousand samples the fused one, whose one launch per depth
 	// instead of three is what counts when a launch holds little work (0.53 against 0.71 ms for 96x64, 4 spp)
-	const bool staged = rp->pipeline == PTX_PIPELINE_STAGED || (rp->pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17)) || sc->dev.n_guards != 0;
+	const uint32_t pipeline = rp->pipeline & ~(uint32_t) PTX_TRACE_ZERO_WEIGHT;
+	A.all_children = (rp->pipeline & PTX_TRACE_ZERO_WEIGHT) ? 1u : 0u;
+	const bool staged = pipeline == PTX_PIPELINE_STAGED || (pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17)) || sc->dev.n_guards != 0;
 	sc->event_tag.clear();
 	sc->event_begin.clear();
 	// profiling: an event after every launch, which is the begin of the next launch as well when that
@@ -1127,6 +1178,7 @@ PtxStatus ptx_primary_hits(PtxScene* sc, const PtxRenderParams* rp, uint32_t sam
 	HIP_TRY(hipSetDevice(sc->device));
 	IntersectArgs A{};
 	camera_basis(sc->camera, *rp, A.cam);
+	root_sees_camera(sc->dev, A.cam);
 	A.sample = sample;
 	return run_intersect(sc, A, (int64_t) rp->width * rp->height, prim, t, nullptr, nullptr, nullptr, nullptr, nullptr);
 }

@@ -106,8 +106,15 @@ struct DevScene {
 	const int2* occ;          // occurrences of the root's children, grouped per child in visiting order: (octant or -1, tie-break key)
 	const int2* root_occ;     // per frame-0 leaf slot: (first occurrence, count)
 	const int4* frame_occ;    // per frame: (first occurrence, count, lowest prim id of the frame, -)
+	// What the reference answers a ray whose direction is NaN in every component (the child rays of a hit whose
+	// normal is NaN, see nan_ray_hit): the first child of the root in visiting order that is not a sphere.
+	int32_t nan_id, nan_frame, nan_slot, nan_extra;  // nan_id < 0: the scene holds nothing but spheres
+	float nan_t;
 	float ambient[3];
 	float root_min[3], root_max[3];
+	// world_transform_inv_ of the root and of an untransformed leaf: the COMPUTED inverse of the identity
+	// (shape.cpp:3-7), whose zero entries carry signs (see enter_identity)
+	float root_winv[16], leaf_winv[16];
 };
 
 struct DevCamera {  // Renderer::render's camera basis, framework/renderer.cpp:27-37
@@ -610,8 +617,31 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 		bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, bias, extra);
 	}
 }
+// A ray whose direction is all NaN.  A box hit whose point matches none of the six faces reports the zero vector
+// as its normal (box.cpp:167-182), Composite::intersect normalises it to NaN (composite.cpp:100), and the
+// reflected / refracted rays of that hit have NaN directions.  The reference does not miss with such a ray: every
+// comparison with NaN is false, so Box::intersect returns a hit at infinite distance (no slab constrains the
+// interval, box.cpp:105-165), Triangle::intersect passes all its rejections and returns distance NaN
+// (triangle.cpp:56-88), a sphere misses (`t > epsilon` is false), every bounds test passes, and
+// Composite::intersect keeps the first child that hits because nothing compares less than it afterwards
+// (composite.cpp:93).  The answer is therefore the same for every such ray: the first leaf in visiting order that
+// is not a sphere, found at scene creation.  With a light in the scene the colour of that hit is NaN, and so is
+// the pixel - also when the hit that spawned the ray lay in shadow and was itself finite.
+__device__ __forceinline__ bool nan_direction(f3 d) { return d.x != d.x && d.y != d.y && d.z != d.z; }
+__device__ __forceinline__ void nan_ray_hit(const DevScene& S, Hit& h) {
+	h.id = S.nan_id;
+	h.frame = S.nan_frame;
+	h.slot = S.nan_slot;
+	h.extra = S.nan_extra;
+	h.t = S.nan_t;
+}
+
 template <bool RB = false>
 __device__ __forceinline__ void trace_closest(const DevScene& S, f3 o, f3 d, int* __restrict__ stk, Hit& best) {
+	if (nan_direction(d)) {
+		nan_ray_hit(S, best);
+		return;
+	}
 	const RayPre pre = ray_pre(S, o, d);
 	NoCount tc;
 	if (!closest_root<RB>(S, o, d, pre, stk, best, tc)) return;
@@ -681,14 +711,48 @@ struct ShadeTables {
 	const Mat16* fwinv;         // per frame
 	const Mat16* fw;            // per frame
 	const float4* mats;         // 4 float4 per material id
+	const float* root_winv;     // DevScene::root_winv / leaf_winv (wave-uniform)
+	const float* leaf_winv;
 };
-__device__ __forceinline__ ShadeTables device_tables(const DevScene& S) { return {S.root_prims, S.root_shade, S.xforms, S.frame_winv, S.frame_w, S.mat_table}; }
+__device__ __forceinline__ ShadeTables device_tables(const DevScene& S) {
+	return {S.root_prims, S.root_shade, S.xforms, S.frame_winv, S.frame_w, S.mat_table, S.root_winv, S.leaf_winv};
+}
 
 // Rebuilds position / normal / ray_direction of the winning leaf exactly as the leaf and
 // the Composites above it would have produced them.  `info` = prim_info of the hit prim (read
 // for mesh triangles only).
+// A Composite hands the ray on to its children as transform_ray(ray, world_transform_inv_) (composite.cpp:83), and
+// every leaf maps it by its own inverse again.  For the root, an octant, an OBJ sub-object or an untransformed
+// triangle that matrix is the computed inverse of the identity: the product leaves every non-zero component as
+// it is, but a zero component may come out with the other sign (the zero entries of the matrix carry signs).
+// Applying it once is the same as applying it any number of times.  Distances and hit decisions never
+// depend on the sign of a zero; the ray direction and position a hit REPORTS do, so the surface rebuild
+// repeats the product - only when some lane of the wave holds a negative zero component at all.
+// (a positive zero comes out of that product as it went in - its own term is +0, and +0 plus any zero is +0 - so
+// only a NEGATIVE zero component can change)
+__device__ __forceinline__ bool has_negative_zero(f3 v) {
+	return __float_as_uint(v.x) == 0x80000000u || __float_as_uint(v.y) == 0x80000000u || __float_as_uint(v.z) == 0x80000000u;
+}
+// the same for a position handed up through a Composite with the identity as world_transform_ (composite.cpp:99):
+// a negative zero becomes a positive one
+__device__ __forceinline__ f3 up_position(f3 p) { return {p.x + 0.0f, p.y + 0.0f, p.z + 0.0f}; }
+
+// ORIGIN_DONE: the origin went through the root's inverse already (the camera position, at set-up)
+template <bool ORIGIN_DONE = false>
 __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, const Hit& h, float4 info) {
 	Surface s;
+	// (all the care for the signs of zeros sits behind wave-wide tests: a sum is a negative zero only if all its
+	// terms are - an exact cancellation gives +0 - so a negative zero in a result needs one among the operands)
+	// the ray as the root's children see it
+	bool zeros = true;
+	if (ORIGIN_DONE) {  // (primary rays, regenerated in registers: the product outright is cheaper than the test around it)
+		d = xform_dir(T.root_winv, d);
+	} else {
+		const bool zero_o = __ballot(has_negative_zero(o)) != 0, zero_d = __ballot(has_negative_zero(d)) != 0;
+		if (zero_o) o = xform_point(T.root_winv, o);
+		if (zero_d) d = xform_dir(T.root_winv, d);
+		zeros = zero_o || zero_d;
+	}
 	if (h.frame == 0) {
 		const DevRootPrim& P = T.prim[h.slot];
 		const DevRootShade& Q = T.shade[h.slot];
@@ -705,6 +769,7 @@ __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, 
 			if (kind == PTX_SPHERE) {  // framework/sphere.cpp:47-48, :54-56
 				s.pos = xform_point(X.w, lo + ld * h.t);
 				s.n = normalize(s.pos - xform_point(X.w, ld3(P.p)));
+				s.pos = up_position(s.pos);  // (after the normal: sphere.cpp forms it from its own position, the root maps the position afterwards)
 			} else {  // framework/box.cpp:98-100
 				f3 nl = box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t);
 				s.n = normalize(xform_dir(X.w, nl));
@@ -713,12 +778,24 @@ __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, 
 			s.rdir = d;
 			for (int k = 0; k < Q.levels_in; ++k) s.n = up_one_level(s.n);  // identity-transform Composites up to the root
 		}
+		if (zeros) s.pos = up_position(s.pos);  // through the root (and any octant above the leaf)
 	} else {
 		const float* Fwinv = T.fwinv[h.frame].m;  // h.frame differs between lanes: per-lane reads
 		const float* Fw = T.fw[h.frame].m;
 		f3 lo = xform_point(Fwinv, o), ld = xform_dir(Fwinv, d);
+		f3 pl = lo + ld * h.t;
+		const bool local_zeros = __ballot(has_negative_zero(lo) || has_negative_zero(ld) || has_negative_zero(pl)) != 0;
+		if (local_zeros) {
+			// Below the mesh's own Composite lie `inside` identity-transform Composites (sub-objects, octants) and
+			// then the triangle.  The triangle reports the direction after its own inverse (triangle.cpp:86) and the
+			// position on the ray it was handed: the mesh-local ray, mapped once more if a Composite lies between.
+			const bool inside = ((__float_as_int(info.w) >> 16) & 0xff) != 0;
+			ld = xform_dir(T.leaf_winv, ld);
+			if (inside) pl = up_position(xform_point(T.leaf_winv, lo) + ld * h.t);
+		}
 		s.n = mk(info.x, info.y, info.z);  // constant per triangle: the whole chain of Composites applied at upload
-		s.pos = xform_point(Fw, lo + ld * h.t);
+		s.pos = xform_point(Fw, pl);
+		if (local_zeros) s.pos = up_position(s.pos);  // through the root (and any octant above the mesh)
 		s.rdir = ld;  // stays in mesh-local space: Composite never maps ray_direction back
 	}
 	return s;
@@ -826,8 +903,8 @@ struct Child {
 // child's colour enters the parent linearly, so weight_child = weight * (factor the
 // reference multiplies it by).  k1 is the factor the reference applies to the local colour
 // after `phong * opacity` (1 when no case applies).
-__device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& M, f3 weight, bool last_depth, Child& refl, Child& refr,
-                                             float& k1) {
+__device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& M, f3 weight, bool last_depth, bool all_children, Child& refl,
+                                             Child& refr, float& k1) {
 	refl.live = false;
 	refr.live = false;
 	k1 = 1.0f;
@@ -875,15 +952,17 @@ __device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& 
 			f3 wt = cmul(weight, M.kd);
 			if (M.glossy > 0.0f) wt = (wt * (1.0f - w_refl)) * (1.0f - M.opacity);
 			else wt = wt * w_refr;
-			if (any_nonzero(wt)) {
-				refr.o = sf.pos - n * (2 * kEps);
-				refr.d = rd * eta + n * (eta * ci - __builtin_sqrtf(k));
-				refr.w = wt;
-				refr.live = true;
-			}
+			// A child whose weight is exactly zero (blue light on a mirror without blue in its ks, say) adds
+			// nothing to the pixel and is not traced, unless the caller asks for every child: the reference traces
+			// it and multiplies what comes back by that zero, which matters in one case only - a NaN from down there
+			// (a box hit that matches no face, box.cpp:167-182) stays a NaN.
+			refr.o = sf.pos - n * (2 * kEps);
+			refr.d = rd * eta + n * (eta * ci - __builtin_sqrtf(k));
+			refr.w = wt;
+			refr.live = all_children || any_nonzero(wt);
 		}
 	}
-	if (want_refl && any_nonzero(wr)) {
+	if (want_refl && (all_children || any_nonzero(wr))) {
 		float ci = -dot(sf.n, sf.rdir);
 		refl.o = sf.pos;
 		refl.d = sf.rdir + (sf.n * ci * 2.0f);
@@ -894,12 +973,12 @@ __device__ __forceinline__ void bounce_terms(const Surface& sf, const Material& 
 
 // Renderer::shade for the fused pipeline: weight * (phong * opacity * k1), children out
 template <bool INTPOW>
-__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, int prim_id, f3 weight, bool last_depth, int* __restrict__ stk,
+__device__ __forceinline__ f3 shade(const DevScene& S, const Surface& sf, int prim_id, f3 weight, bool last_depth, bool all_children, int* __restrict__ stk,
                                     Child& refl, Child& refr, unsigned& n_shadow) {
 	Material M = load_material(S, prim_id);
 	f3 c = phong<INTPOW>(S, sf, M, stk, n_shadow) * M.opacity;
 	float k1;
-	bounce_terms(sf, M, weight, last_depth, refl, refr, k1);
+	bounce_terms(sf, M, weight, last_depth, all_children, refl, refr, k1);
 	c = c * k1;
 	return cmul(weight, c);
 }
@@ -1040,6 +1119,7 @@ struct BounceArgs {
 	unsigned ns, s0;           // samples per pixel in this render's range, first sample
 	unsigned depth;
 	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
+	unsigned all_children;     // also trace child rays of exactly zero weight (PTX_TRACE_ZERO_WEIGHT)
 	float* accum;
 	Counters* counters;        // overflow flag only
 	unsigned long long* stat;  // work counters, spread over kStatWaves slots
@@ -1200,7 +1280,7 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 		refl.live = refr.live = false;
 		if (hit) {
 			Surface sf = surface_of(A.S, o, d, h);
-			contrib = shade<INTPOW>(A.S, sf, h.id, w, A.last_depth != 0, stk, refl, refr, cnt_shadow);
+			contrib = shade<INTPOW>(A.S, sf, h.id, w, A.last_depth != 0, A.all_children != 0, stk, refl, refr, cnt_shadow);
 			++cnt_hits;
 		}
 		accumulate(A.accum, pix, contrib, hit);
@@ -1334,8 +1414,9 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) v
 			input_ray<PRIMARY>(A, ref, o, d, w, pix);
 		}
 		RayPre pre = ray_pre(A.S, o, d);
+		const bool nan_ray = !PRIMARY && active && nan_direction(d);  // (see nan_ray_hit)
 		if (active) {
-			if (closest_root<RB>(A.S, o, d, pre, stk, h, tc)) frames = frame_mask(A.S, o, d, pre, tc);
+			if (!nan_ray && closest_root<RB>(A.S, o, d, pre, stk, h, tc)) frames = frame_mask(A.S, o, d, pre, tc);
 			++cnt_trace;
 		}
 		bool park = frames != 0;
@@ -1349,6 +1430,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) v
 			park = false;
 		}
 		if (RB && !park) hit_key_to_id(A.S, h);  // (a parked ray keeps its key until its mesh walks are done)
+		if (nan_ray) nan_ray_hit(A.S, h);
 		if (PRIMARY) {
 			emit(h.id >= 0 && !park, h, ref);
 		} else {  // the step's own hits: placed now, stored at the top of the next step
@@ -1446,15 +1528,18 @@ __device__ __forceinline__ void fill_shade_lds(ShadeLds<LT>& lds, const DevScene
 	}
 }
 
+#ifndef PTX_SHADE0_WAVES
+#define PTX_SHADE0_WAVES 4
+#endif
 template <bool PRIMARY, bool INTPOW, bool LT>
-__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? 4 : 3) void k_shade(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3) void k_shade(BounceArgs A) {
 	__shared__ ShadeLds<LT> lds;
 	extern __shared__ float4 stage_mem[];
 	if (LT) {
 		fill_shade_lds(lds, A.S);
 		__syncthreads();
 	}
-	const ShadeTables T = LT ? ShadeTables{lds.prim, lds.shade, lds.xf, lds.fwinv, lds.fw, lds.mats} : device_tables(A.S);
+	const ShadeTables T = LT ? ShadeTables{lds.prim, lds.shade, lds.xf, lds.fwinv, lds.fw, lds.mats, A.S.root_winv, A.S.leaf_winv} : device_tables(A.S);
 	ShadeStage stage;
 	{
 		float4* p = stage_mem + (threadIdx.x >> 6) * shade_stage_f4(A.stage_children, A.stage_lights);
@@ -1577,10 +1662,10 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? 4 : 3) void k_shade(B
 				w = mk(ray.b.z, ray.b.w, ray.c.x);
 				pix = __float_as_uint(ray.c.y);
 			}
-			sf = surface_of(T, o, d, h, info);
+			sf = surface_of<PRIMARY>(T, o, d, h, info);
 			for (int k = 0; k < h.extra; ++k) sf.n = up_one_level(sf.n);  // octants of a split root above the child (composite.cpp:100)
 			const Material M = material_of(T, h, info);
-			bounce_terms(sf, M, w, A.last_depth != 0, refl, refr, k1);
+			bounce_terms(sf, M, w, A.last_depth != 0, A.all_children != 0, refl, refr, k1);
 			kd = M.kd;
 			ks = M.ks;
 			mm = M.m;

@@ -1,0 +1,121 @@
+"""Generated scenes for the parity tests: every seed gives one scene file (SDF text) with a random
+mix of spheres, boxes and triangles directly under the root - few (the leaf list), some dozens (the
+BVH over the frame-0 leaves) or more than 64 (a root the reference splits into octants) - half of
+them translated, rotated (also by exact quarter turns, whose matrices carry exact and negative
+zeros) and scaled (also unevenly), sometimes a mesh from the fixtures, an enclosing room or not,
+one to three lights, materials of every shading case (Phong only, mirror, glass, both).
+The same text goes to the reference build, to the CPU oracle and to the product."""
+import numpy as np
+
+f32 = np.float32
+N_SHAPES = (3, 9, 16, 17, 30, 64, 65, 90, 130)
+MESHES = ("sword", "superhot")
+
+
+def scene_text(seed):
+    rng = np.random.default_rng(1000 + seed)
+    lines = []
+    mats = []
+    for k in range(6):
+        ka, kd, ks = rng.uniform(0, 1, 3), rng.uniform(0, 1, 3), rng.uniform(0, 1, 3)
+        m = [0, 1, 8, 50, 500, 2.5][k] if seed % 2 else [20, 0, 3, 100, 7.25, 1][k]
+        glossy = [0, 0.3, 1, 0, 0.5, 0][k]
+        opacity = [1, 1, 1, 0.4, 0.2, 1][k]
+        ior = [1, 1, 1, 1.3, 1.5, 1][k]
+        name = f"m{k}"
+        mats.append(name)
+        lines.append("define material %s %s %g %g %g %g" % (name, " ".join(f"{v:.3f}" for v in (*ka, *kd, *ks)), m, glossy, opacity, ior))
+    n = N_SHAPES[seed % len(N_SHAPES)]
+    tf = []
+    for k in range(n):
+        x, y, z = rng.uniform(-8, 8), rng.uniform(-4, 4), rng.uniform(-25, -6)
+        mat = mats[int(rng.integers(0, len(mats)))]
+        kind = int(rng.integers(0, 3))
+        name = "sbt"[kind] + f"{k:03d}"
+        local = rng.random() < 0.5      # defined around the origin and moved by its transform, or defined in place
+        cx, cy, cz = (0.0, 0.0, 0.0) if local else (x, y, z)
+        if kind == 0:
+            lines.append(f"define shape sphere {name} {cx:.3f} {cy:.3f} {cz:.3f} {rng.uniform(0.3, 1.4):.3f} {mat}")
+        elif kind == 1:
+            e = rng.uniform(0.3, 1.6, 3)
+            lines.append(f"define shape box {name} {cx - e[0]:.3f} {cy - e[1]:.3f} {cz - e[2]:.3f} {cx + e[0]:.3f} {cy + e[1]:.3f} {cz + e[2]:.3f} {mat}")
+        else:
+            p = rng.uniform(-1.5, 1.5, 9)
+            lines.append(f"define shape triangle {name} " + " ".join(f"{v:.3f}" for v in (p[0] + cx, p[1] + cy, p[2] + cz, p[3] + cx, p[4] + cy, p[5] + cz,
+                                                                                              p[6] + cx, p[7] + cy, p[8] + cz)) + f" {mat}")
+        if local:
+            tf.append(f"transform {name} translate {x:.3f} {y:.3f} {z:.3f}")
+        r = rng.random()
+        if r < 0.25:
+            tf.append(f"transform {name} rotate {rng.uniform(-180, 180):.1f} {rng.uniform(-90, 90):.1f} {rng.uniform(-180, 180):.1f}")
+        elif r < 0.35:
+            q = rng.integers(-2, 3, 3) * 90
+            tf.append(f"transform {name} rotate {q[0]} {q[1]} {q[2]}")
+        r = rng.random()
+        if r < 0.2:
+            tf.append(f"transform {name} scale {rng.uniform(0.4, 1.8):.2f} {rng.uniform(0.4, 1.8):.2f} {rng.uniform(0.4, 1.8):.2f}")
+        elif r < 0.3:
+            s = rng.uniform(0.5, 1.5)
+            tf.append(f"transform {name} scale {s:.2f} {s:.2f} {s:.2f}")
+        if not local and rng.random() < 0.15:
+            tf.append(f"transform {name} translate {rng.uniform(-2, 2):.2f} {rng.uniform(-1, 1):.2f} {rng.uniform(-2, 2):.2f}")
+    if seed % 3 != 2:
+        lines.append(f"define shape box room -11 -6 -30 11 6 8 {mats[0]}")
+    if seed % 2 == 0:
+        mesh = MESHES[(seed // 2) % len(MESHES)]
+        lines.append(f"define shape obj {mesh}")
+        tf.append(f"transform {mesh} translate {rng.uniform(-3, 3):.2f} {rng.uniform(-4, -1):.2f} {rng.uniform(-16, -9):.2f}")
+        if seed % 4 == 0:
+            tf.append(f"transform {mesh} rotate {rng.uniform(-90, 90):.1f} {rng.uniform(-40, 40):.1f} 0")
+        else:
+            tf.append(f"transform {mesh} rotate 90 0 -90")
+        s = rng.uniform(0.5, 1.1)
+        tf.append(f"transform {mesh} scale {s:.2f} {s:.2f} {s * (1.0 if seed % 8 else 1.4):.2f}")
+    for k in range(1 + seed % 3):
+        lines.append(f"define light l{k} {rng.uniform(-8, 8):.2f} {rng.uniform(2, 5.5):.2f} {rng.uniform(-20, 4):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.5, 1.5):.2f}")
+    lines.append("define ambient amb 1 1 1 0.15")
+    lines.append("define camera eye 60 0 0 5 0 0 0")
+    return "\n".join(lines + tf) + "\n"
+
+
+def rays(seed, n_random=12000, n_axis=3000):
+    """Random rays through the region of the shapes, and rays with one or two direction components
+    exactly zero (the branch of the box test for rays parallel to a slab, the divisions by zero
+    everywhere else), some of them starting exactly on a lattice of round coordinates."""
+    rng = np.random.default_rng(7000 + seed)
+    o = rng.uniform((-10, -5, -28), (10, 5, 6), size=(n_random, 3)).astype(f32)
+    d = rng.normal(size=(n_random, 3)).astype(f32)
+    d *= (rng.uniform(0.5, 2.0, size=(n_random, 1)) / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+    oa = rng.uniform((-10, -5, -28), (10, 5, 6), size=(n_axis, 3)).astype(f32)
+    oa[::3] = np.round(oa[::3])
+    da = rng.normal(size=(n_axis, 3)).astype(f32)
+    zero = rng.integers(0, 3, n_axis)
+    da[np.arange(n_axis), zero] = 0.0
+    two = rng.random(n_axis) < 0.5
+    da[np.arange(n_axis)[two], (zero[two] + 1) % 3] = 0.0
+    da[::7] *= -1.0     # (negative zeros among the zero components)
+    # rays whose direction is NaN (the children of a hit with a NaN normal): the reference answers them all alike
+    on = rng.uniform((-10, -5, -28), (10, 5, 6), size=(16, 3)).astype(f32)
+    dn = np.full((16, 3), np.nan, f32)
+    return np.concatenate([o, oa, on]), np.concatenate([d, da, dn]).astype(f32)
+
+
+def same_bits_or_both_nan(a, b):
+    a, b = np.asarray(a, f32), np.asarray(b, f32)
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+def write_scene(seed, folder, fixtures_sdf):
+    """The scene of `seed` as <folder>/sdf/gen<seed>.sdf with the fixture meshes linked beside it (the
+    reference opens OBJ files at ../../sdf/ relative to a working directory below the folder that
+    holds sdf/; the oracle and the product take the folder as an argument).  Returns (file, obj_dir)."""
+    import os
+    d = os.path.join(str(folder), "sdf")
+    os.makedirs(d, exist_ok=True)
+    for f in os.listdir(fixtures_sdf):
+        if f.endswith((".obj", ".mtl")) and not os.path.exists(os.path.join(d, f)):
+            os.symlink(os.path.join(fixtures_sdf, f), os.path.join(d, f))
+    path = os.path.join(d, f"gen{seed}.sdf")
+    with open(path, "w") as fh:
+        fh.write(scene_text(seed))
+    return path, d + "/"

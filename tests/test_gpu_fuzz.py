@@ -1,0 +1,61 @@
+"""Device parity on generated scenes (tests/fuzz_scenes.py), through the C ABI.
+
+Eighteen scenes: 3 to 130 spheres, boxes and triangles under the root (the leaf list, the BVH over
+the frame-0 leaves, roots the reference splits into octants), random and quarter-turn rotations,
+even and uneven scales, meshes with turned and unevenly scaled transforms, with and without an
+enclosing room, one to three lights, every shading case.  The CPU oracle is checked against the
+real reference on these very scenes in tests/test_oracle.py
+(test_oracle_equals_reference_on_generated_scenes); here the device must give the oracle's
+answers: hit identity exact, t / position / normal / ray_direction bit-identical - on primary
+rays, random rays and rays with zero direction components (also negative zeros) - and images to
+the usual bar in both pipelines."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import beq
+from test_gpu_parity import PIPELINES, assert_image_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (more seeds for a longer sweep)
+def test_generated_scene(pt, port, tmp_path, seed):
+    from fuzz_scenes import rays, same_bits_or_both_nan, write_scene
+    sdf, obj_dir = write_scene(seed, tmp_path, pt.SDF_DIR)
+    hs = pt.HostScene(sdf, obj_dir)
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    s = port.load(sdf, obj_dir)
+    assert hs.prim_paths() == port.leaf_paths(s)
+    o1, d1 = port.primary_rays(s, 120, 80, 1)
+    o2, d2 = rays(seed)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    assert m.sum() > 300
+    # bit-identical; a NaN (the normal of a box hit that matches no face, box.cpp:167-182; everything about the
+    # hit of a ray with a NaN direction) is a NaN in both
+    for k in ("t", "pos", "raydir", "normal"):
+        assert same_bits_or_both_nan(a[k][m], b[k][m]), k
+    assert m[-16:].all() or not m[-16:].any()       # the NaN rays all get one answer
+    ref = port.render(s, 96, 64, 2, 4, counters=True)
+    for pipeline in PIPELINES:
+        r = ds.render_image(96, 64, 2, 4, pipeline=pipeline)
+        # NaN pixels (NaN normals) are the reference's.  The comparison leaves out pixels whose colour sum is
+        # negative (materials with random coefficients give such sums): tone mapping c / (c + 1) has a pole at -1,
+        # which turns a last-bit difference of the sums into any amount.
+        finite = np.isfinite(ref["color"]).all(axis=2)
+        assert np.array_equal(np.isfinite(r["color"]).all(axis=2), finite)
+        assert finite.mean() > 0.9
+        ok = finite & (ref["color"] >= 0).all(axis=2) & (ref["color"] < 1).all(axis=2)
+        assert ok.mean() > 0.5
+        assert_image_close(np.where(ok[..., None], r["color"], 0), np.where(ok[..., None], ref["color"], 0),
+                           np.where(ok[..., None], r["rgb"], 0), np.where(ok[..., None], ref["rgb"], 0))
+        bad = finite & ~ok      # there: the same sums to a few units in the last place, seen through the inverse of the tone map
+        ca, cb = r["color"][bad].astype(np.float64), ref["color"][bad].astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ia, ib = ca / (1 - ca), cb / (1 - cb)
+        assert (np.isclose(ia, ib, rtol=2e-5, atol=2e-6) | np.isclose(ca, cb, rtol=0, atol=2e-7)).all()      # (sums in the millions map to 1 - one unit in the last place)
+    ds.close()

@@ -121,3 +121,37 @@ def test_reference_side_flatten_equals_the_mirror():
         pytest.skip("oracle/_ref/libref.so absent")
     r = subprocess.run([sys.executable, os.path.join(REPO, "oracle", "check_flatten.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (more seeds for a longer sweep)
+def test_oracle_equals_reference_on_generated_scenes(port, tmp_path, seed):
+    """The generated scenes of the device parity tests (tests/fuzz_scenes.py: leaf lists of 3 to 130
+    shapes with random and quarter-turn transforms, split roots, meshes, every material case) through
+    the real reference and through the oracle: the same hit object, bit-identical distance,
+    position, normal and ray direction on primary rays, random rays and rays with zero direction
+    components, and a bit-identical small image.  Container-only (needs oracle/_ref/libref.so); it
+    is what makes the oracle a pinned checker on these scenes too."""
+    from fuzz_scenes import rays, same_bits_or_both_nan, write_scene
+    from oracle_lib import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref/libref.so absent")
+    ref = Reference()
+    from oracle_lib import SDF_DIR
+    sdf, obj_dir = write_scene(seed, tmp_path, SDF_DIR)
+    s, r = port.load(sdf, obj_dir), ref.load(sdf)
+    leaf = port.leaf_names(s)
+    o1, d1 = port.primary_rays(s, 60, 40, 1)
+    o2, d2 = rays(seed, 4000, 1500)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = port.intersect(s, o, d), ref.intersect(r, o, d)
+    assert np.array_equal(a["hit"], b["hit"])
+    m = a["hit"]
+    assert m.sum() > 100
+    assert [leaf[k] for k in a["rank"][m]] == [n for n, h in zip(b["names"], m) if h]
+    for k in ("t", "pos", "raydir", "normal"):      # a NaN (box hit that matches no face, box.cpp:167-182; rays with a NaN direction) is a NaN in both
+        assert same_bits_or_both_nan(a[k][m], b[k][m]), k
+    assert m[-16:].all()       # the reference answers a ray whose direction is NaN with a hit
+    ia, ib = port.render(s, 72, 48, 2, 4), ref.render(r, 72, 48, 2, 4, ppm_path=str(tmp_path / "ref.ppm"))
+    assert np.array_equal(ia["rgb"], ib["rgb"])
+    ca, cb = ia["color"], ib["color"]
+    assert ((ca.view(np.uint32) == cb.view(np.uint32)) | (np.isnan(ca) & np.isnan(cb))).all()
