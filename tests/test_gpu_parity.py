@@ -165,6 +165,23 @@ def test_work_counters(pt, port, scenes):
     assert st["shaded_hits"] <= st["trace_rays"]
 
 
+def test_every_child_ray_on_request(pt, port, scenes):
+    """PTX_TRACE_ZERO_WEIGHT: child rays of exactly zero weight are traced as well (example.sdf has
+    them: light that passed the blue-only glass meets the mirror without blue in its ks).  Then the
+    closest-hit queries number exactly what the reference's Renderer::trace is called, in both
+    pipelines; without the flag there are fewer, and the image is the same either way."""
+    w, h, aa, nb = 120, 68, 2, 5
+    ds = scenes.device_scene("example_fixed")
+    ref = port.render(scenes.oracle_scene("example_fixed"), w, h, aa, nb, counters=True)
+    for pipeline in PIPELINES:
+        lean = ds.render_image(w, h, aa, nb, pipeline=pipeline)
+        full = ds.render_image(w, h, aa, nb, pipeline=pipeline, zero_weight=True)
+        assert full["stats"]["trace_rays"] == int(ref["counters"][0])
+        assert lean["stats"]["trace_rays"] < full["stats"]["trace_rays"]
+        assert_image_close(full["color"], ref["color"], full["rgb"], ref["rgb"])
+        assert_image_close(lean["color"], full["color"], lean["rgb"], full["rgb"])
+
+
 def test_edge_cases(pt, tmp_path):
     # no shapes at all: every ray misses, image is black
     sdf = tmp_path / "empty.sdf"
