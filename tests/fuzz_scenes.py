@@ -59,6 +59,16 @@ def scene_text(seed):
             tf.append(f"transform {name} scale {s:.2f} {s:.2f} {s:.2f}")
         if not local and rng.random() < 0.15:
             tf.append(f"transform {name} translate {rng.uniform(-2, 2):.2f} {rng.uniform(-1, 1):.2f} {rng.uniform(-2, 2):.2f}")
+    if seed % 5 == 0:
+        # ties: boxes on a lattice that share whole faces, and exact copies of a box and a triangle under later names
+        # (equal distances: the reference keeps the child it met first, composite.cpp:93)
+        for k in range(4):
+            x0 = -4 + 2 * k
+            lines.append(f"define shape box lat{k} {x0} -1 -12 {x0 + 2} 1 -10 {mats[k % len(mats)]}")
+        lines.append(f"define shape box twin_a -7 2 -15 -5 3 -13 {mats[1]}")
+        lines.append(f"define shape box twin_b -7 2 -15 -5 3 -13 {mats[2]}")
+        lines.append(f"define shape triangle twin_c 3 2 -9 6 2 -9 4 4 -9 {mats[3]}")
+        lines.append(f"define shape triangle twin_d 3 2 -9 6 2 -9 4 4 -9 {mats[4]}")
     if seed % 3 != 2:
         lines.append(f"define shape box room -11 -6 -30 11 6 8 {mats[0]}")
     if seed % 2 == 0:
@@ -74,7 +84,13 @@ def scene_text(seed):
     for k in range(1 + seed % 3):
         lines.append(f"define light l{k} {rng.uniform(-8, 8):.2f} {rng.uniform(2, 5.5):.2f} {rng.uniform(-20, 4):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.5, 1.5):.2f}")
     lines.append("define ambient amb 1 1 1 0.15")
-    lines.append("define camera eye 60 0 0 5 0 0 0")
+    if seed % 4 == 1:     # a camera that looks along no axis, rolled
+        lines.append(f"define camera eye {rng.uniform(40, 90):.1f} {rng.uniform(-3, 3):.2f} {rng.uniform(-2, 3):.2f} {rng.uniform(3, 7):.2f} "
+                     f"{rng.uniform(-25, 25):.1f} {rng.uniform(-15, 15):.1f} {rng.uniform(-30, 30):.1f}")
+    elif seed % 4 == 3:   # quarter turns: camera matrices with exact and negative zeros
+        lines.append(f"define camera eye 60 0 0 5 0 0 {(seed // 4 % 4) * 90}")
+    else:
+        lines.append("define camera eye 60 0 0 5 0 0 0")
     return "\n".join(lines + tf) + "\n"
 
 

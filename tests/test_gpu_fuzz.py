@@ -40,9 +40,10 @@ def test_generated_scene(pt, port, tmp_path, seed):
     for k in ("t", "pos", "raydir", "normal"):
         assert same_bits_or_both_nan(a[k][m], b[k][m]), k
     assert m[-16:].all() or not m[-16:].any()       # the NaN rays all get one answer
-    ref = port.render(s, 96, 64, 2, 4, counters=True)
+    w, h, aa, nb = ((96, 64, 2, 4), (97, 61, 3, 6), (64, 48, 1, 8))[seed % 3]      # (odd sizes, odd sample grids, deeper trees)
+    ref = port.render(s, w, h, aa, nb, counters=True)
     for pipeline in PIPELINES:
-        r = ds.render_image(96, 64, 2, 4, pipeline=pipeline)
+        r = ds.render_image(w, h, aa, nb, pipeline=pipeline)
         # NaN pixels (NaN normals) are the reference's.  The comparison leaves out pixels whose colour sum is
         # negative (materials with random coefficients give such sums): tone mapping c / (c + 1) has a pole at -1,
         # which turns a last-bit difference of the sums into any amount.
