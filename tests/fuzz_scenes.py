@@ -81,6 +81,11 @@ def scene_text(seed):
             tf.append(f"transform {mesh} rotate 90 0 -90")
         s = rng.uniform(0.5, 1.1)
         tf.append(f"transform {mesh} scale {s:.2f} {s:.2f} {s * (1.0 if seed % 8 else 1.4):.2f}")
+    if seed % 6 == 4:     # a second, large mesh with its own materials (16 008 faces, 11 sub-objects, deep octrees)
+        lines.append("define shape obj colored-buster")
+        tf.append(f"transform colored-buster translate {rng.uniform(-4, 4):.2f} {rng.uniform(-3, 0):.2f} {rng.uniform(-20, -12):.2f}")
+        tf.append(f"transform colored-buster rotate {rng.uniform(-180, 180):.1f} {rng.uniform(-60, 60):.1f} {rng.uniform(-90, 90):.1f}")
+        tf.append("transform colored-buster scale .14 .14 .14")
     for k in range(1 + seed % 3):
         lines.append(f"define light l{k} {rng.uniform(-8, 8):.2f} {rng.uniform(2, 5.5):.2f} {rng.uniform(-20, 4):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.5, 1.5):.2f}")
     lines.append("define ambient amb 1 1 1 0.15")
