@@ -7,7 +7,8 @@ flattens the same file.  The two PtxSceneDesc must agree byte for byte: frames (
 bounds, levels_up), prims in tie-break order (kind, parameters, normal, matrices, material index,
 frame, levels_in), materials, lights, ambient, camera, the octants of a split root and the child
 entries under them in visiting order (split_root.sdf: 120 shapes and a mesh under the root); and
-the leaf names in the same order.
+the leaf names in the same order.  The same for the generated scenes of the parity tests
+(tests/fuzz_scenes.py; PTX_FUZZ_SEEDS of them, 18 by default).
 Exit code 0 = identical for every scene."""
 import ctypes as C
 import importlib
@@ -50,8 +51,8 @@ def ref_parts(ref, scene):
     return out, names
 
 
-def mirror_parts(pt, path):
-    hs = pt.HostScene(path)
+def mirror_parts(pt, path, hs=None):
+    hs = hs or pt.HostScene(path)
     d = hs.desc.contents
     out = {
         "frames": (d.n_frames, C.string_at(d.frames, d.n_frames * C.sizeof(pt.PtxFrame))),
@@ -109,6 +110,22 @@ def main():
                         bad = np.nonzero(x != y)[0]
                         per = len(x) // max(a[k][0], 1)
                         print(f"   {k}: {len(bad)} bytes differ, first in element {bad[0] // per} at byte {bad[0] % per}")
+    # the generated scenes of the parity tests (tests/fuzz_scenes.py): random and quarter-turn transforms, split roots, two meshes
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from fuzz_scenes import write_scene
+    tmp = tempfile.mkdtemp()
+    bad = []
+    n_gen = int(os.environ.get("PTX_FUZZ_SEEDS", "18"))
+    for seed in range(n_gen):
+        path, obj_dir = write_scene(seed, tmp, SDF_DIR)
+        a, an = ref_parts(ref, ref.load(path))
+        hs = pt.HostScene(path, obj_dir)
+        b, bn = mirror_parts(pt, path, hs)
+        if not (all(a[k] == b[k] for k in PARTS) and an == bn):
+            bad.append(seed)
+    print(f"generated scenes 0..{n_gen - 1}: " + ("all ==" if not bad else f"!= for seeds {bad}"))
+    ok = ok and not bad
     print("IDENTICAL" if ok else "DIFFERENT")
     return 0 if ok else 1
 
