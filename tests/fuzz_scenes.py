@@ -19,6 +19,8 @@ def scene_text(seed):
     for k in range(6):
         ka, kd, ks = rng.uniform(0, 1, 3), rng.uniform(0, 1, 3), rng.uniform(0, 1, 3)
         m = [0, 1, 8, 50, 500, 2.5][k] if seed % 2 else [20, 0, 3, 100, 7.25, 1][k]
+        if seed % 3 == 0:
+            m = int(m)      # whole-number exponents only: the kernels' square-and-multiply power instead of pow()
         glossy = [0, 0.3, 1, 0, 0.5, 0][k]
         opacity = [1, 1, 1, 0.4, 0.2, 1][k]
         ior = [1, 1, 1, 1.3, 1.5, 1][k]
