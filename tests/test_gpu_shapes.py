@@ -155,13 +155,14 @@ def test_rotated_and_scaled_root_shapes(pt, port, tmp_path):
         assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
 
 
-def test_full_size_properties_mesh(pt, scenes):
+def test_full_size_properties_mesh(pt, port, scenes):
     """BASELINE configs[2] at its full size (cornell + buster_sword, 16 008 triangles, 1920x1080,
     1024 spp, 5 bounces: 2.1 G samples, 9 G rays; the CPU oracle would need hours).  The staged
     pipeline with the library's default queue memory (8 GiB: a hundred chunks of primary samples per image, the
     parked mesh walks under full load), the staged pipeline in 2 GiB (hundreds of chunks) and the
     fused pipeline agree to the image bar and count exactly the same rays, shadow rays and hits
-    at every depth; the image is the sum of eight ranks' sample ranges."""
+    at every depth; the image is the sum of eight ranks' sample ranges; two windows of it equal the
+    oracle's pixels at the full sample count."""
     import importlib
     import torch
     hs = scenes.host_scene("cornell_buster")
@@ -189,6 +190,16 @@ def test_full_size_properties_mesh(pt, scenes):
     torch.cuda.synchronize()
     assert_image_close(color.cpu().numpy().reshape(h, w, 3), a["color"], rgb.cpu().numpy().reshape(h, w, 3), a["rgb"])
     assert np.isfinite(a["color"]).all() and (a["color"] >= 0).all()
+    # two windows of the full-size image against the oracle at the full 1024 samples per pixel: one on the mesh
+    # and the glass box (deep trees), one on a wall
+    s = scenes.oracle_scene("cornell_buster")
+    for x0, y0 in ((1180, 420), (300, 800)):
+        nx, ny = 6, 4
+        sc = port.sample_colors(s, w, h, aa, nb, x0, y0, nx, ny)        # (ny, nx, spp, 3), un-tone-mapped
+        mean = sc.astype(np.float64).sum(axis=2) / (aa * aa)
+        want = (mean / (mean + 1)).astype(np.float32)                    # tone_map_color, renderer.cpp:286-291
+        got = a["color"][y0:y0 + ny, x0:x0 + nx]
+        assert float(np.sqrt(np.mean((got - want) ** 2))) <= 1e-6 and float(np.abs(got - want).max()) <= 1e-5
     ds.close()
     small = pt.DeviceScene(hs, 0, 2 << 30)
     c = small.render_image(w, h, aa, nb, pipeline="staged")
