@@ -66,4 +66,19 @@ def test_generated_scene(pt, port, tmp_path, seed):
         with np.errstate(divide="ignore", invalid="ignore"):
             ia, ib = ca[rest] / (1 - ca[rest]), cb[rest] / (1 - cb[rest])
         assert (np.isclose(ia, ib, rtol=1e-3, atol=2e-6) | np.isclose(ca[rest], cb[rest], rtol=0, atol=2e-7)).all()      # (sums in the millions map to 1 - one unit in the last place)
+    if seed % 3 == 2:
+        # a larger image of the deepest trees in the smallest work memory (96 MiB: a launch takes a slice of every
+        # segment and the rest of a depth is traced in further launches) against the same image in ample memory
+        W, H, AA = 640, 400, 2
+        tiny = pt.DeviceScene(hs, 0, 1)
+        big = ds.render_image(W, H, AA, nb, pipeline="staged")
+        fin = np.isfinite(big["color"]).all(axis=2)
+        for pipeline in PIPELINES:
+            q = tiny.render_image(W, H, AA, nb, pipeline=pipeline)
+            assert q["stats"]["trace_rays"] == big["stats"]["trace_rays"] and q["stats"]["shadow_rays"] == big["stats"]["shadow_rays"]
+            assert np.array_equal(np.isfinite(q["color"]).all(axis=2), fin)
+            close = np.isclose(q["color"], big["color"], rtol=0, atol=1e-5).all(axis=2) | ~fin
+            assert close.mean() >= 0.997        # (ill-conditioned pixels aside, see above)
+        assert tiny.render_image(W, H, AA, nb, pipeline="staged")["stats"]["launches"] > big["stats"]["launches"]
+        tiny.close()
     ds.close()
