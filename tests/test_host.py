@@ -66,6 +66,27 @@ def test_split_root_lists_its_octants(pt, port):
         assert e.n_guards == 0 and e.n_occurrences == 0
 
 
+def test_odd_but_valid_scene_text(pt, port):
+    """What the reference's `>>` parsing accepts (fixtures/sdf/odd_syntax.sdf): exponents, leading '+' and '.', a
+    trailing '.', runs of blanks, a leading tab, tokens after the last operand, an unknown line, a negative radius
+    (Sphere takes its absolute value, sphere.cpp:10), a second shape under a name already taken (dropped,
+    composite.cpp:105-110).  The mirror reads the same scene: four leaves in name order with the reference's values
+    (the byte-for-byte comparison with the reference's own loader is oracle/check_flatten.py); the oracle's
+    loader agrees."""
+    hs = pt.HostScene(pt.SDF_DIR + "/odd_syntax.sdf")
+    d = hs.desc.contents
+    assert hs.prim_names() == ["b1", "s1", "t1", "tabbed"] == port.leaf_names(port.load(pt.SDF_DIR + "/odd_syntax.sdf"))
+    s1 = d.prims[1]
+    assert list(s1.p)[:4] == [0.0, 1.5, -8.0, 1.25] and list(s1.world)[12:15] == [1.0, 2.0, -3.0]
+    assert d.n_materials == 2
+    mats = {d.prims[i].material for i in range(d.n_prims)}
+    a = d.materials[d.prims[1].material]
+    assert list(a.ks) == [1.0, 1.0, 1.0] and a.m == 20.0
+    b = d.materials[d.prims[0].material]
+    assert list(b.ka) == [0.5, 0.5, 0.5] and list(b.kd) == [1.0, 0.25, 0.75] and (b.glossy, b.opacity, b.ior) == (np.float32(0.3), 1.0, np.float32(1.3))
+    assert mats == {0, 1} and d.camera.fov_x == 45.0
+
+
 def test_octree_statistics_of_the_mesh_scenes(pt, scenes):
     """Octree shape of the reference build: buster_sword 16 008 faces -> 790 composites,
     36 927 leaf entries; colored-buster keeps 15 959 of its 16 008 faces (octant rounding
