@@ -311,6 +311,33 @@ def test_split_root_is_answered_through_its_octants(pt, port, tmp_path):
         db.close()
 
 
+@pytest.mark.parametrize("name", ["odd_syntax", "odd_mesh"])
+def test_hand_written_fixtures(pt, port, name):
+    """The two hand-written fixtures (oddly formatted scene text; an OBJ with faces in every index form, triangles
+    directly under the mesh and in sub-objects, MTL materials of every illumination model the loader knows) on
+    the device against the oracle, which equals the reference on them (tests/test_oracle.py)."""
+    from fuzz_scenes import same_bits_or_both_nan
+    from oracle_lib import random_rays
+    path = f"{pt.SDF_DIR}/{name}.sdf"
+    hs = pt.HostScene(path)
+    ds, s = pt.DeviceScene(hs, 0, 1 << 27), port.load(path)
+    assert hs.prim_paths() == port.leaf_paths(s)
+    o1, d1 = port.primary_rays(s, 150, 100, 1)
+    o2, d2 = random_rays(30000, 3, lo=(-5, -3, -14), hi=(5, 5, 4))
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    assert m.sum() > 1000
+    for k in ("t", "pos", "raydir", "normal"):
+        assert same_bits_or_both_nan(a[k][m], b[k][m]), k
+    ref = port.render(s, 150, 100, 2, 5)
+    for pipeline in PIPELINES:
+        r = ds.render_image(150, 100, 2, 5, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    ds.close()
+
+
 def test_full_size_4k_configs(pt, port, scenes):
     """BASELINE configs[3] (superhot + coloured buster, 3840x2160, 4096 spp: 34 G samples) in full on
     this one GPU, and of configs[4] (cornell + buster_sword, 3840x2160, 10 000 spp over 8 GPUs) the
