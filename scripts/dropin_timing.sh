@@ -13,6 +13,11 @@ for scene in example cornell_buster; do
     echo "== $scene run $rep"; cat $OUT/dropin_$scene.$rep.log
   done
 done
+# the same program under the kernel tracer: which kernels the drop-in path runs (the program itself after --, no wrapper)
+export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dropin_trace -- path-tracer_amd/pt_example $SDF/cornell_buster.sdf /tmp/traced.ppm 1920 1080 32 5 $SDF/ > $OUT/dropin_traced.log 2>&1 || { echo "traced pt_example failed"; tail -5 $OUT/dropin_traced.log; exit 1; }
+cp $(ls $OUT/dropin_trace/*/*kernel_stats.csv | head -1) $OUT/dropin_kernel_stats.csv
+echo "== kernels of the drop-in run"; head -7 $OUT/dropin_kernel_stats.csv | cut -c1-150
 python3 - <<'PY'
 import importlib, sys, time
 sys.path.insert(0, '.')
