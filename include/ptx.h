@@ -12,7 +12,7 @@
  * The reference has no FFI layer of its own; the seam is the C++ class Renderer
  * (framework/renderer.hpp:22-62).  A host-side Renderer with that class's signatures
  * flattens its Scene (framework/scene.hpp:13-21) into a PtxSceneDesc and calls the
- * functions below; INTEGRATION.md shows the binding.
+ * functions below (path-tracer_amd/csrc/host/renderer.cpp and flatten.cpp are a working binding).
  *
  * Conventions
  *   - every function returns a PtxStatus; ptx_last_error() gives the message of the

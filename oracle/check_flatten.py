@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE, container-only (needs oracle/_ref/libref.so, i.e. the reference checkout
 at build time).  For every fixture scene: the reference's own load_scene builds its Scene; the
-hand-over of INTEGRATION.md written against the REFERENCE's classes (oracle/ref_flatten.cpp)
+scene hand-over (Scene -> PtxSceneDesc) written against the REFERENCE's classes (oracle/ref_flatten.cpp)
 flattens it; the product's host mirror (libpt_host.so: its own loader, octree and flatten)
 flattens the same file.  The two PtxSceneDesc must agree byte for byte: frames (matrices,
 bounds, levels_up), prims in tie-break order (kind, parameters, normal, matrices, material index,

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY (container-only: compiled together with the unmodified reference
-// sources into _ref/libref.so, see oracle/Makefile).  The scene hand-over of INTEGRATION.md
+// sources into _ref/libref.so, see oracle/Makefile).  The scene hand-over (flattening a Scene into the arrays of include/ptx.h)
 // written against the REFERENCE's own classes (glm types, std::map children, shared_ptr
 // materials): walks a Scene loaded by the reference's load_scene and fills the PtxSceneDesc
 // arrays of include/ptx.h.  oracle/check_flatten.py compares the result byte for byte with
