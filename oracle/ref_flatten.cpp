@@ -143,7 +143,7 @@ struct Walker {
 			Composite const* sub = as_composite(s);
 			if (!sub) {
 				emit_leaf(s, 0, levels);
-				out.occurrences.push_back(PtxOccurrence{guard, seen.at(&s), 0, 0});
+				if (out.prims[(size_t) seen.at(&s)].frame == 0) out.occurrences.push_back(PtxOccurrence{guard, seen.at(&s), 0, 0});
 				continue;
 			}
 			if (is_identity(sub->world_transform_) && !only_plain_triangles(*sub)) {

@@ -119,7 +119,9 @@ struct Walker {
 			if (s.kind() != Shape::Kind::composite) {
 				++out.leaf_entries;
 				emit_leaf(s, 0, levels, path);
-				out.occurrences.push_back(PtxOccurrence{guard, seen.at(&s), 0, 0});
+				// (a triangle that was first met inside an octant holding nothing but plain triangles belongs to that
+				// octant's frame, which every ray that can hit it enters: its later entries need no listing)
+				if (out.prims[(size_t) seen.at(&s)].frame == 0) out.occurrences.push_back(PtxOccurrence{guard, seen.at(&s), 0, 0});
 				continue;
 			}
 			auto const& sub = static_cast<Composite const&>(s);

@@ -20,7 +20,7 @@ from test_gpu_parity import PIPELINES, assert_image_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (more seeds for a longer sweep)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_FIRST", "0")), int(os.environ.get("PTX_FUZZ_FIRST", "0")) + int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (PTX_FUZZ_FIRST / PTX_FUZZ_SEEDS: a longer sweep)
 def test_generated_scene(pt, port, tmp_path, seed):
     from fuzz_scenes import rays, same_bits_or_both_nan, write_scene
     sdf, obj_dir = write_scene(seed, tmp_path, pt.SDF_DIR)

@@ -123,7 +123,7 @@ def test_reference_side_flatten_equals_the_mirror():
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (more seeds for a longer sweep)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_FIRST", "0")), int(os.environ.get("PTX_FUZZ_FIRST", "0")) + int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (PTX_FUZZ_FIRST / PTX_FUZZ_SEEDS: a longer sweep)
 def test_oracle_equals_reference_on_generated_scenes(port, tmp_path, seed):
     """The generated scenes of the device parity tests (tests/fuzz_scenes.py: leaf lists of 3 to 130
     shapes with random and quarter-turn transforms, split roots, meshes, every material case) through
