@@ -60,8 +60,9 @@ def test_generated_scene(pt, port, tmp_path, seed):
         err = np.where(ok[..., None], np.abs(ca - cb), 0).max(axis=2)
         good = ok & (err <= 1e-5)
         assert good.sum() >= 0.997 * ok.sum()
+        rows = good[::-1, :, None]      # (the 8-bit rows run top-down as in the PPM, the colour buffer bottom-up)
         assert_image_close(np.where(good[..., None], r["color"], 0), np.where(good[..., None], ref["color"], 0),
-                           np.where(good[..., None], r["rgb"], 0), np.where(good[..., None], ref["rgb"], 0))
+                           np.where(rows, r["rgb"], 0), np.where(rows, ref["rgb"], 0))
         rest = finite & ~good
         with np.errstate(divide="ignore", invalid="ignore"):
             ia, ib = ca[rest] / (1 - ca[rest]), cb[rest] / (1 - cb[rest])
