@@ -3,7 +3,7 @@ mix of spheres, boxes and triangles directly under the root - few (the leaf list
 BVH over the frame-0 leaves) or more than 64 (a root the reference splits into octants) - half of
 them translated, rotated (also by exact quarter turns, whose matrices carry exact and negative
 zeros) and scaled (also unevenly), sometimes a mesh from the fixtures, an enclosing room or not,
-one to three lights, materials of every shading case (Phong only, mirror, glass, both).
+none to five lights, materials of every shading case (Phong only, mirror, glass, both).
 The same text goes to the reference build, to the CPU oracle and to the product."""
 import numpy as np
 
@@ -101,7 +101,7 @@ def scene_text(seed):
         tf.append(f"transform colored-buster translate {L(rng.uniform(-4, 4), rng.uniform(-3, 0), rng.uniform(-20, -12))}")
         tf.append(f"transform colored-buster rotate {rng.uniform(-180, 180):.1f} {rng.uniform(-60, 60):.1f} {rng.uniform(-90, 90):.1f}")
         tf.append(f"transform colored-buster scale {.14 * S:.7g} {.14 * S:.7g} {.14 * S:.7g}")
-    for k in range(1 + seed % 3):
+    for k in range({7: 0, 9: 5}.get(seed % 11, 1 + seed % 3)):      # (one to three lights; now and then none, or five)
         lines.append(f"define light l{k} {L(rng.uniform(-8, 8), rng.uniform(2, 5.5), rng.uniform(-20, 4))} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.3, 1):.2f} {rng.uniform(.5, 1.5):.2f}")
     lines.append("define ambient amb 1 1 1 0.15")
     if seed % 4 == 1:     # a camera that looks along no axis, rolled
