@@ -296,6 +296,17 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 				return fail(PTX_ERR_INVALID, "occurrence " + std::to_string(k) + ": names no octant, or neither a frame-0 leaf nor a mesh frame");
 		}
 	}
+	// ---- every index and count the set-up below and the kernels rely on, before anything touches a device
+	for (int f = 1; f < D->n_frames; ++f)
+		if (D->frames[f].levels_up < 1 || D->frames[f].levels_up > 255)
+			return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": levels_up out of range");
+	for (int i = 0; i < D->n_prims; ++i) {
+		const PtxPrim& P = D->prims[i];
+		if (P.kind < 0 || P.kind > 2) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": unknown kind");
+		if (P.frame < 0 || P.frame >= D->n_frames) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": frame out of range");
+		if (P.material < 0 || P.material >= D->n_materials) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": material out of range");
+		if (P.levels_in < 0 || P.levels_in > 255) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": levels_in out of range");
+	}
 	int ndev = ptx_device_count();
 	if (ndev <= 0) return fail(PTX_ERR_DEVICE, "no HIP device: this library has no CPU path");
 	if (device < 0 || device >= ndev) return fail(PTX_ERR_INVALID, "device index out of range");
@@ -379,10 +390,6 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	}
 	for (int i = 0; i < D->n_prims; ++i) {
 		const PtxPrim& P = D->prims[i];
-		if (P.kind < 0 || P.kind > 2) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": unknown kind");
-		if (P.frame < 0 || P.frame >= D->n_frames) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": frame out of range");
-		if (P.material < 0 || P.material >= D->n_materials) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": material out of range");
-		if (P.levels_in < 0 || P.levels_in > 255) return fail(PTX_ERR_INVALID, "prim " + std::to_string(i) + ": levels_in out of range");
 		int packed = P.material | (P.levels_in << 16);
 		float pw;
 		std::memcpy(&pw, &packed, 4);
@@ -474,7 +481,6 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		std::memcpy(G.bmax, F.bounds_max, sizeof G.bmax);
 		G.levels_up = F.levels_up;
 		G.plain = pure_translation(F.world) && pure_translation(F.world_inv);
-		if (F.levels_up < 1 || F.levels_up > 255) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": levels_up out of range");
 		auto const& ids = frame_tris[f];
 		G.has_prims = !ids.empty();
 		if (ids.empty()) continue;

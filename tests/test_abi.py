@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from conftest import REPO
@@ -99,4 +101,47 @@ def test_malformed_octant_lists_are_rejected_without_a_device(pt):
         st, msg = attempt(change)
         assert st == 1 and word in msg, (change.__name__, st, msg)
     st, msg = attempt(lambda d, g, o: None)           # the untouched description gets as far as the device
+    assert st == (0 if pt.device_count() > 0 else 3), msg
+
+
+def test_corrupted_descriptions_are_rejected_without_a_device(pt):
+    """Every index and count of a scene description is checked before anything touches a device: a
+    description with one field pushed out of range - a prim's kind, frame, material or level count, a
+    frame's level count or parent, a negative count, a missing array - comes back as PTX_ERR_INVALID /
+    PTX_ERR_UNSUPPORTED with the offender named, never as a crash or a set-up that loops."""
+    L = pt.ptx_lib()
+    hs = pt.HostScene(pt.SDF_DIR + "/cornell_buster.sdf")
+    good = hs.desc.contents
+    assert good.n_frames == 2 and good.n_prims > 16000
+
+    def attempt(change):
+        prims = (pt.PtxPrim * good.n_prims).from_buffer_copy(ctypes.string_at(good.prims, ctypes.sizeof(pt.PtxPrim) * good.n_prims))
+        frames = (pt.PtxFrame * good.n_frames)(*[good.frames[i] for i in range(good.n_frames)])
+        d = type(good).from_buffer_copy(good)
+        d.prims, d.frames = prims, frames
+        change(d, prims, frames)
+        out = ctypes.c_void_p()
+        st = L.ptx_scene_create(ctypes.byref(d), 0, 0, ctypes.byref(out))
+        return st, L.ptx_last_error().decode()
+
+    rng = np.random.default_rng(5)
+    cases = []
+    for field, values in (("kind", (-1, 3, 1 << 30)), ("frame", (-1, 2, 1 << 30)), ("material", (-1, good.n_materials, 1 << 30)),
+                          ("levels_in", (-1, 256, (1 << 31) - 1))):
+        for v in values:
+            i = int(rng.integers(0, good.n_prims))
+            cases.append((lambda d, p, f, i=i, field=field, v=v: setattr(p[i], field, v), f"prim {i}"))
+    for v in (0, 256, (1 << 31) - 1):
+        cases.append((lambda d, p, f, v=v: setattr(f[1], "levels_up", v), "frame 1"))
+    cases.append((lambda d, p, f: setattr(f[1], "parent", 1), "parent"))
+    cases.append((lambda d, p, f: setattr(f[0], "parent", 0), "frame 0"))
+    cases.append((lambda d, p, f: setattr(d, "n_prims", -5), "negative"))
+    cases.append((lambda d, p, f: setattr(d, "n_lights", -1), "negative"))
+    cases.append((lambda d, p, f: setattr(d, "n_frames", 0), "frame 0"))
+    cases.append((lambda d, p, f: setattr(d, "materials", None), "NULL"))
+    cases.append((lambda d, p, f: setattr(d, "n_materials", 70000), "materials"))
+    for change, word in cases:
+        st, msg = attempt(change)
+        assert st in (1, 2) and word in msg, (st, msg, word)
+    st, msg = attempt(lambda d, p, f: None)
     assert st == (0 if pt.device_count() > 0 else 3), msg
