@@ -156,3 +156,37 @@ def write_scene(seed, folder, fixtures_sdf):
     with open(path, "w") as fh:
         fh.write(scene_text(seed))
     return path, d + "/"
+
+
+def full_size_findings(pt, seed, folder, W=1920, H=1080, AA=4):
+    """The scene of `seed` at a full image size: the staged pipeline in ample work memory against the
+    fused one and against both in the smallest work memory - the same rays, shadow rays and hits per
+    depth, the same image to the bar of the parity tests (pixels near the pole of the tone mapping
+    compared before it, at most eight at the end of the float range).  No oracle: a consistency check
+    of the queue driving under load.  Returns the findings as text lines."""
+    sdf, obj_dir = write_scene(seed, folder, pt.SDF_DIR)
+    hs = pt.HostScene(sdf, obj_dir)
+    nb = (4, 6, 8)[seed % 3]
+    big, tiny = pt.DeviceScene(hs, 0, 1 << 32), pt.DeviceScene(hs, 0, 1)
+    found = []
+    try:
+        ref = big.render_image(W, H, AA, nb, pipeline="staged")
+        fin = np.isfinite(ref["color"]).all(axis=2)
+        rb = ref["color"].astype(np.float64)
+        for ds, name, pipeline in ((big, "ample", "fused"), (tiny, "smallest", "staged"), (tiny, "smallest", "fused")):
+            if pipeline == "fused" and hs.desc.contents.n_guards:
+                continue        # (a split root always takes the staged kernels)
+            q = ds.render_image(W, H, AA, nb, pipeline=pipeline)
+            same = all(q["stats"][k] == ref["stats"][k] for k in ("trace_rays", "shadow_rays", "shaded_hits", "per_depth_rays"))
+            odd = np.isfinite(q["color"]).all(axis=2) != fin
+            qa = q["color"].astype(np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                close = (np.isclose(qa, rb, rtol=0, atol=1e-5).all(axis=2) | ~fin | odd
+                         | np.isclose(qa / (1 - qa), rb / (1 - rb), rtol=1e-5, atol=0).all(axis=2))
+            if not (same and odd.sum() <= 8 and close.mean() >= 0.997):
+                found.append(f"seed {seed}, {name} work memory, {pipeline}: counts equal {same}, finite masks differ in {odd.sum()} pixels, "
+                             f"{close.mean():.5f} of the pixels agree")
+    finally:
+        big.close()
+        tiny.close()
+    return found

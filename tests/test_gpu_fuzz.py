@@ -111,3 +111,11 @@ def test_generated_scene(pt, port, tmp_path, seed):
         assert tiny.render_image(W, H, AA, nb, pipeline="staged")["stats"]["launches"] > big["stats"]["launches"]
         tiny.close()
     ds.close()
+
+
+@pytest.mark.parametrize("seed", (4, 10, 17, 23))      # (two meshes; a split root with a mesh; five lights; deep trees)
+def test_generated_scene_at_full_size(pt, tmp_path, seed):
+    """1920x1080, 16 spp: both pipelines, ample and smallest work memory - the same counts per depth, the
+    same image (scripts/fuzz_big.py sweeps more scenes the same way)."""
+    from fuzz_scenes import full_size_findings
+    assert full_size_findings(pt, seed, tmp_path) == []
