@@ -134,6 +134,8 @@ struct PtxScene {
 	std::vector<void*> allocs;
 	WorkMem work;
 	std::vector<unsigned> tails;   // host copy of the tail counters a render reads back (sized once, at creation)
+	float* accum_copy = nullptr;   // the caller's accumulation buffer as it was before a render (scenes with two-child materials)
+	size_t accum_copy_floats = 0;
 	Counters host_counters{};
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
@@ -731,6 +733,7 @@ void ptx_scene_destroy(PtxScene* scene) {
 	if (!scene) return;
 	(void) hipSetDevice(scene->device);
 	for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
+	if (scene->accum_copy) (void) hipFree(scene->accum_copy);
 	for (void* p : scene->allocs) (void) hipFree(p);
 	delete scene;
 }
@@ -751,9 +754,11 @@ PtxStatus ptx_scene_info(const PtxScene* sc, int32_t* n_frames, int32_t* n_prims
 namespace {
 
 // One render into d_accum with the work memory `M` (the scene's own block, or any other that
-// holds the same parts).  Calls no allocating routine unless profiling has to create events.
+// holds the same parts).  Calls no allocating routine unless profiling has to create events
+// (may_create_events) or the straight way through the image needs its copy of the accumulation
+// buffer (allow_straight; see below).
 PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParams* rp, float* d_accum, hipStream_t stream, int check_overflow,
-                            PtxStats* stats, bool may_create_events) {
+                            PtxStats* stats, bool may_create_events, bool allow_straight) {
 	BounceArgs A{};
 	A.S = sc->dev;
 	camera_basis(sc->camera, *rp, A.cam);
@@ -819,25 +824,36 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	// segment and nothing can overflow, whatever the materials do.
 	unsigned per_ray = sc->branching ? 2u : 1u;
 	if (staged) per_ray = std::max(per_ray, (unsigned) std::max(sc->dev.n_lights, 1));
-	const unsigned nqueues = std::max(max_depth, 1u);
-	// slots of one queue: the memory holds `nqueues` ray queues (+ shadow queue and hit records
-	// for the staged pipeline: 48 + 16 bytes more per slot); record indices stay below 2^31
-	const uint64_t capd = std::min<uint64_t>(M.qslots * 48 / (48ull * nqueues + (staged ? 64 : 0)), 1ull << 30);
-	// Segments = waves of every grid: kMaxSeg (four rounds of the resident workgroups) for a
-	// large render; fewer for a small one, so that every wave still gets some eight 64-sample
-	// steps of the first chunk and the steps of the deeper depths stay reasonably full; fewer,
-	// too, when the memory is small, so that a segment still takes whole steps.
-	unsigned n_seg = M.max_seg;
-	while (n_seg > 64 && (total + 63) / 64 < (uint64_t) n_seg * 8) n_seg >>= 1;
-	while (n_seg > 4 && capd / n_seg / per_ray < 64) n_seg >>= 1;
-	const unsigned seg_cap = (unsigned) (capd / n_seg) & ~63u;
-	unsigned take = std::min((seg_cap / per_ray) & ~63u, (1u << 30) / n_seg);  // records of a segment per launch
-	if (max_depth == 0 && !staged) take = (1u << 26) / n_seg;                 // nothing is queued at all
-	if (take < 64) return fail(PTX_ERR_NOMEM, "the work memory is too small for max_ray_bounces and the number of lights of this scene");
-	const uint64_t chunk = (uint64_t) take * n_seg;  // primary samples per launch (at most 2^30)
-	const dim3 grid(n_seg / (kBlock / 64));
-	A.seg_cap = seg_cap;
-	A.n_seg = n_seg;
+	// Two ways through the image.
+	//   straight: every depth of every primary chunk is launched once, back to back, and the host never looks
+	//     at a count.  Depth d reads the queue depth d-1 wrote and that queue is dead afterwards, so two ray
+	//     queues take turns and the memory goes into larger chunks.  What this cannot do is come back for the
+	//     rays a launch had to leave behind: a segment that holds more than `take` records - deep trees of
+	//     two-child materials only; a one-child material never hands on more rays than it took.  The kernel
+	//     that sees such a segment raises Counters::remainder, and the image is rendered again the careful
+	//     way, into the accumulation buffer as it was before (a copy taken first).
+	//   careful: one queue per depth, the counts read back after every primary chunk, remainders traced
+	//     deepest depth first (below).  Also the only way with work memory the library does not own
+	//     (no room for the copy), and with the fused pipeline.
+	const bool can_remain = sc->branching && max_depth > 0;
+	bool straight = staged && max_depth > 0 && allow_straight;
+	if (straight && can_remain) {
+		const size_t need = (size_t) rp->width * rp->height * 3;
+		if (sc->accum_copy_floats < need) {
+			if (sc->accum_copy) (void) hipFree(sc->accum_copy);
+			sc->accum_copy = nullptr;
+			sc->accum_copy_floats = 0;
+			if (hipMalloc(reinterpret_cast<void**>(&sc->accum_copy), need * sizeof(float)) == hipSuccess) sc->accum_copy_floats = need;
+			else {
+				(void) hipGetLastError();
+				straight = false;  // no room for the copy: the careful way needs none
+			}
+		}
+		if (straight) HIP_TRY(hipMemcpyAsync(sc->accum_copy, d_accum, need * sizeof(float), hipMemcpyDeviceToDevice, stream));
+	}
+	unsigned nqueues = 0, n_seg = 0, seg_cap = 0, take = 0, take0 = 0;
+	uint64_t capd = 0, chunk = 0;
+	dim3 grid(1);
 	auto queue_at = [&](unsigned index) {  // queue `index` of the block: capd slots of 48 bytes, as three planes
 		RayQueue q;
 		q.a = M.qmem + (uint64_t) index * capd * 3;
@@ -845,10 +861,37 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		q.c = reinterpret_cast<float2*>(q.b + capd);
 		return q;
 	};
-	if (staged) {  // shadow queue and hit records behind the ray queues
-		A.shadow = queue_at(nqueues);
-		A.hits = M.qmem + ((uint64_t) nqueues + 1) * capd * 3;
-	}
+	auto size_queues = [&](bool two_queues) -> PtxStatus {
+		nqueues = two_queues ? std::min(max_depth, 2u) : std::max(max_depth, 1u);
+		// slots of one queue: the memory holds `nqueues` ray queues (+ shadow queue and hit records
+		// for the staged pipeline: 48 + 16 bytes more per slot); record indices stay below 2^31
+		capd = std::min<uint64_t>(M.qslots * 48 / (48ull * nqueues + (staged ? 64 : 0)), 1ull << 30);
+		// Segments = waves of every grid: kMaxSeg (four rounds of the resident workgroups) for a
+		// large render; fewer for a small one, so that every wave still gets some eight 64-sample
+		// steps of the first chunk and the steps of the deeper depths stay reasonably full; fewer,
+		// too, when the memory is small, so that a segment still takes whole steps.
+		n_seg = M.max_seg;
+		while (n_seg > 64 && (total + 63) / 64 < (uint64_t) n_seg * 8) n_seg >>= 1;
+		while (n_seg > 4 && capd / n_seg / per_ray < 64) n_seg >>= 1;
+		seg_cap = (unsigned) (capd / n_seg) & ~63u;
+		take = std::min((seg_cap / per_ray) & ~63u, (1u << 30) / n_seg);  // records of a segment per launch
+		if (max_depth == 0 && !staged) take = (1u << 26) / n_seg;         // nothing is queued at all
+		if (take < 64) return fail(PTX_ERR_NOMEM, "the work memory is too small for max_ray_bounces and the number of lights of this scene");
+		// Straight with two-child materials: the primary launch takes half of what a launch may take, so that a
+		// segment whose rays all hit such a material (its next depths then hold twice its primary samples, where
+		// the image as a whole holds a fraction) still goes through every depth in one launch each.  Only trees
+		// that keep doubling leave a remainder then.
+		take0 = two_queues && can_remain ? std::max(64u, (take / 2) & ~63u) : take;
+		chunk = (uint64_t) take0 * n_seg;  // primary samples per launch (at most 2^30)
+		grid = dim3(n_seg / (kBlock / 64));
+		A.seg_cap = seg_cap;
+		A.n_seg = n_seg;
+		if (staged) {  // shadow queue and hit records behind the ray queues
+			A.shadow = queue_at(nqueues);
+			A.hits = M.qmem + ((uint64_t) nqueues + 1) * capd * 3;
+		}
+		return PTX_OK;
+	};
 	auto launch_depth = [&](unsigned d) -> PtxStatus {
 		if (!staged) {
 			HIP_TRY(tick(0, d, true));
@@ -896,15 +939,16 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		return PTX_OK;
 	};
 
-	// Driving the ray tree through the queues: queue d (1..max_depth) holds the rays traced at
-	// depth d.  Every depth of a primary chunk is first launched once, back to back, each wave
-	// reading its segment's count on the device and taking at most `take` rays of it; the host
-	// then reads the counts ONCE per primary chunk.  Only if some segment of a depth held more
-	// than `take` rays (deep trees of two-child materials) is the remainder traced, deepest
-	// depth first - the queues below a depth are free by then - slice by slice with the counts
-	// read back after every launch (depth-first over the slices).  Every wave of a launch
-	// writes its counts, so nothing needs clearing in between.
+	// Driving the ray tree through the queues: the rays traced at depth d (1..max_depth) wait in
+	// queue d-1 (careful) or in one of two queues taking turns (straight).  Every depth of a
+	// primary chunk is first launched once, back to back, each wave reading its segment's count
+	// on the device and taking at most `take` rays of it.  The careful way then reads the counts
+	// ONCE per primary chunk, and if some segment of a depth held more than `take` rays the
+	// remainder is traced, deepest depth first - the queues below a depth are free by then -
+	// slice by slice with the counts read back after every launch (depth-first over the slices).
+	// Every wave of a launch writes its counts, so nothing needs clearing in between.
 	unsigned* tails = sc->tails.data();
+	bool two_queues = false;
 	auto set_depth = [&](unsigned d, unsigned first, unsigned n_take) {
 		const bool last = (d == max_depth);
 		A.depth = d;
@@ -913,8 +957,9 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		A.in_take = n_take;
 		A.in_count = count_of(d);
 		A.out_count = count_of(d + 1);
-		if (d > 0) A.in = queue_at(d - 1);
-		A.out = queue_at(last ? 0 : d);
+		A.flag_remainder = two_queues && can_remain ? 1u : 0u;
+		if (d > 0) A.in = queue_at(two_queues ? (d - 1) & 1u : d - 1);
+		A.out = queue_at(last ? 0 : (two_queues ? d & 1u : d));
 	};
 	auto fullest = [&](const unsigned* t) {  // records in the fullest segment
 		unsigned m = 0;
@@ -941,25 +986,50 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		}
 		return PTX_OK;
 	};
-	for (uint64_t first = 0; first < total; first += chunk) {
-		A.first_pix = (unsigned) (first / ns);
-		A.first_s = (unsigned) (first % ns);
-		A.batch = (unsigned) std::min<uint64_t>(chunk, total - first);
-		for (unsigned d = 0; d <= max_depth; ++d) {
-			set_depth(d, 0, take);
-			PtxStatus ls = launch_depth(d);
-			if (ls != PTX_OK) return ls;
+	auto image = [&](bool straight_way) -> PtxStatus {
+		two_queues = straight_way;
+		PtxStatus zs = size_queues(two_queues);
+		if (zs != PTX_OK) return zs;
+		for (uint64_t first = 0; first < total; first += chunk) {
+			A.first_pix = (unsigned) (first / ns);
+			A.first_s = (unsigned) (first % ns);
+			A.batch = (unsigned) std::min<uint64_t>(chunk, total - first);
+			for (unsigned d = 0; d <= max_depth; ++d) {
+				set_depth(d, 0, take);
+				PtxStatus ls = launch_depth(d);
+				if (ls != PTX_OK) return ls;
+			}
+			if (max_depth == 0 || straight_way) continue;
+			HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * M.max_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			chained = false;
+			unsigned held[kMaxBounces + 2] = {0};
+			for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * M.max_seg);
+			for (unsigned d = max_depth; d >= 1; --d) {
+				if (held[d] <= take) continue;
+				PtxStatus rst = run(run, d, take, held[d]);
+				if (rst != PTX_OK) return rst;
+			}
 		}
-		if (max_depth == 0) continue;
-		HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * M.max_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+		return PTX_OK;
+	};
+	{
+		PtxStatus is = image(straight);
+		if (is != PTX_OK) return is;
+	}
+	if (straight && can_remain) {
+		// did any launch leave rays behind?  (one word, the only thing the host waits for)
+		unsigned long long left = 0;
+		HIP_TRY(hipMemcpyAsync(&left, &M.counters->remainder, sizeof left, hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
 		chained = false;
-		unsigned held[kMaxBounces + 2] = {0};
-		for (unsigned d = 1; d <= max_depth; ++d) held[d] = fullest(tails + (size_t) (d - 1) * M.max_seg);
-		for (unsigned d = max_depth; d >= 1; --d) {
-			if (held[d] <= take) continue;
-			PtxStatus rst = run(run, d, take, held[d]);
-			if (rst != PTX_OK) return rst;
+		if (left) {
+			HIP_TRY(hipMemcpyAsync(d_accum, sc->accum_copy, (size_t) rp->width * rp->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+			HIP_TRY(hipMemsetAsync(M.counters, 0, kCounterBytes, stream));
+			HIP_TRY(hipMemsetAsync(M.stat, 0, kStatBytes, stream));
+			// (the launches of the discarded pass stay in `launches` and in the profiling events: they cost their time)
+			PtxStatus is = image(false);
+			if (is != PTX_OK) return is;
 		}
 	}
 	HIP_TRY(hipGetLastError());
@@ -1010,7 +1080,7 @@ PtxStatus ptx_render_accumulate(PtxScene* sc, const PtxRenderParams* rp, float* 
 	PtxStatus st = check_params(rp);
 	if (st != PTX_OK) return st;
 	HIP_TRY(hipSetDevice(sc->device));
-	return render_accumulate(sc, sc->work, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats, true);
+	return render_accumulate(sc, sc->work, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats, true, true);
 }
 
 PtxStatus ptx_render_accumulate_static(PtxScene* sc, const PtxRenderParams* rp, float* d_accum, void* stream_, int check_overflow,
@@ -1039,7 +1109,7 @@ PtxStatus ptx_render_accumulate_static(PtxScene* sc, const PtxRenderParams* rp, 
 	M.max_seg = kStaticSeg;
 	M.qmem = reinterpret_cast<float4*>(base + kStaticQueueOff);
 	M.qslots = ((kStaticBytes - kStaticQueueOff) / 48) & ~127ull;
-	return render_accumulate(sc, M, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats, false);
+	return render_accumulate(sc, M, rp, d_accum, static_cast<hipStream_t>(stream_), check_overflow, stats, false, false);
 }
 
 PtxStatus ptx_resolve(int device, const float* d_accum, uint32_t w, uint32_t h, uint32_t spp, float* d_color, uint8_t* d_rgb8,
@@ -1428,7 +1498,7 @@ PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, cons
 		PtxStats* ps = stats ? stats + r : nullptr;
 		if (ps) std::memset(ps, 0, sizeof *ps);
 		if (part.sample_begin < part.sample_end) {
-			PtxStatus rs = render_accumulate(sc, sc->work, &part, w.d_accum, nullptr, 1, ps, true);
+			PtxStatus rs = render_accumulate(sc, sc->work, &part, w.d_accum, nullptr, 1, ps, true, true);
 			if (rs != PTX_OK) return bad(rs, ptx_last_error());
 		}
 		e = hipStreamSynchronize(nullptr);

@@ -145,6 +145,7 @@ struct Hit {
 constexpr int kTestKinds = 5;  // slab tests, triangle tests, sphere tests, box tests, ray transforms
 struct Counters {  // cumulative over one ptx_render_accumulate (filled by k_stats_reduce)
 	unsigned long long trace_rays, shadow_rays, shaded_hits, overflow;
+	unsigned long long remainder;  // waves that found more records in their segment than a launch could take (see flag_remainder)
 	unsigned long long per_depth[kMaxDepthSlots];
 	unsigned long long per_depth_shadow[kMaxDepthSlots];
 	unsigned long long per_depth_hits[kMaxDepthSlots];
@@ -1120,6 +1121,7 @@ struct BounceArgs {
 	unsigned depth;
 	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
 	unsigned all_children;     // also trace child rays of exactly zero weight (PTX_TRACE_ZERO_WEIGHT)
+	unsigned flag_remainder;   // depth > 0: count the waves whose segment holds more than the launch takes (nobody comes back for the rest)
 	float* accum;
 	Counters* counters;        // overflow flag only
 	unsigned long long* stat;  // work counters, spread over kStatWaves slots
@@ -1144,6 +1146,17 @@ struct BounceArgs {
 // wait there (pipeline_wait) is free.
 __device__ __forceinline__ void pipeline_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // s_waitcnt vmcnt(0)
 
+// Kernel arguments read in place.  BounceArgs is some 900 bytes, far more than the hundred scalar registers of a
+// wave: taken by value, the compiler loads every member it will ever need once, at the top of the kernel, and then
+// keeps what does not fit in the lanes of a vector register - a v_readlane per use inside the loop (the shading
+// kernels executed about a hundred of them per 64-record step) and a dozen vector registers to hold them.  The
+// queue kernels therefore read the arguments where the launch put them, through a pointer into the kernel-argument
+// segment (constant address space: scalar loads that hit the scalar cache), and hide that pointer from the
+// optimiser once per step, so that a member is loaded in the step that uses it and its register is free again
+// afterwards.  (The by-value parameter stays in the signature: it is what puts the bytes there.)
+typedef const __attribute__((address_space(4))) struct BounceArgs KArgs;
+#define PTX_ARGS_IN_PLACE(ka) KArgs* ka = (KArgs*) __builtin_amdgcn_kernarg_segment_ptr()
+#define PTX_ARGS_AGAIN(ka) asm volatile("" : "+s"(ka))
 // this wave's number: the same in every lane, and known to the compiler to be (scalar registers, scalar loads)
 __device__ __forceinline__ unsigned wave_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)); }
 
@@ -1321,7 +1334,9 @@ constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from whi
 #define PTX_PRIMARY_WAVES 5
 #endif
 template <bool PRIMARY, bool RB, class TC>
-__global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A_) {
+	PTX_ARGS_IN_PLACE(ka);
+#define A (*(const BounceArgs*) ka)
 	__shared__ int lds_stack[kStack * kBlock];
 	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
 	int* stk = lds_stack + threadIdx.x;
@@ -1330,6 +1345,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) v
 	const unsigned wave = wave_id();
 	unsigned n;
 	const unsigned steps = wave_steps<PRIMARY>(A, wave, n);
+	if (!PRIMARY && A.flag_remainder && A.in_take && lane == 0 && min(A.in_count[wave], A.seg_cap) > A.in_first + A.in_take) atomicAdd(&A.counters->remainder, 1ull);
 	float4* const my_hits = A.hits + (size_t) wave * A.seg_cap;
 	unsigned n_hit = 0;
 	unsigned cnt_trace = 0;
@@ -1390,6 +1406,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) v
 	bool pend = false;
 	if (!PRIMARY && steps) fetch(0);
 	for (unsigned k = 0; k < steps; ++k) {
+		PTX_ARGS_AGAIN(ka);
 		unsigned ref;
 		const bool active = step_record<PRIMARY>(A, wave, n, k, lane, ref);
 		Hit h;
@@ -1460,6 +1477,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) v
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 0, cnt_trace);
 	stat_add_tests(st, 3, tc);
+#undef A
 }
 
 // The shading kernel as a pipeline (see pipeline_wait): at the TOP of step k the wave
@@ -1532,7 +1550,9 @@ __device__ __forceinline__ void fill_shade_lds(ShadeLds<LT>& lds, const DevScene
 #define PTX_SHADE0_WAVES 4
 #endif
 template <bool PRIMARY, bool INTPOW, bool LT>
-__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3) void k_shade(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3) void k_shade(BounceArgs A_) {
+	PTX_ARGS_IN_PLACE(ka);
+#define A (*(const BounceArgs*) ka)
 	__shared__ ShadeLds<LT> lds;
 	extern __shared__ float4 stage_mem[];
 	if (LT) {
@@ -1621,6 +1641,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3)
 	float4 hit_cur = hit_next;
 	hit_next = fetch_hit(1);
 	for (unsigned k = 0; k < steps; ++k) {
+		PTX_ARGS_AGAIN(ka);
 		pipeline_wait();
 		const float4 hr = hit_cur, info = info_next;
 		const RayRec ray = ray_next;
@@ -1749,6 +1770,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3)
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 1, cnt_shadow);
 	stat_add(st, 2, cnt_hits);
+#undef A
 }
 
 // find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
@@ -1757,7 +1779,9 @@ template <bool RB, class TC>
 #ifndef PTX_SHADOW_WAVES
 #define PTX_SHADOW_WAVES 5
 #endif
-__global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A) {
+__global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
+	PTX_ARGS_IN_PLACE(ka);
+#define A (*(const BounceArgs*) ka)
 	__shared__ int lds_stack[kStack * kBlock];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
@@ -1780,6 +1804,7 @@ __global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs 
 	f3 prev_c = {0, 0, 0};
 	bool prev_lit = false;
 	for (unsigned k = 0; k < steps; ++k) {
+		PTX_ARGS_AGAIN(ka);
 		pipeline_wait();
 		const float4 a = next_a, b = next_b;
 		accumulate(A.accum, prev_pix, prev_c, prev_lit);
@@ -1812,6 +1837,7 @@ __global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs 
 	}
 	accumulate(A.accum, prev_pix, prev_c, prev_lit);
 	stat_add_tests(stat_slot(A, wave), 3 + kTestKinds, tc);
+#undef A
 }
 
 // sums the statistic slots of one depth into the compact block the host reads
