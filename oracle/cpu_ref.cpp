@@ -991,14 +991,29 @@ void oracle_sample_colors(void* s, unsigned w, unsigned h, unsigned aa, unsigned
 	Renderer R{*sc, w, h, aa, bounces};
 	CameraBasis cb = camera_basis(sc->camera, w);
 	float aa_unit = 1.0f / aa;
-	size_t k = 0;
-	for (unsigned y = y0; y < y0 + ny; ++y)
-		for (unsigned x = x0; x < x0 + nx; ++x)
-			for (int aax = 0; aax < (int) aa; ++aax)
-				for (int aay = 0; aay < (int) aa; ++aay) {
-					Color c = R.trace(primary_ray(cb, w, h, x, y, aax, aay, aa_unit));
-					out[k++] = c.r; out[k++] = c.g; out[k++] = c.b;
-				}
+	// every sample stands alone, so the rows of the sample grid (one pixel, one aax) are dealt to the host's threads
+	const size_t rows = (size_t) nx * ny * aa;
+	size_t nthreads = std::max(1u, std::thread::hardware_concurrency());
+	if (const char* e = std::getenv("OMP_NUM_THREADS"))  // the share of the machine this process was given, where one is set
+		if (std::atoi(e) > 0) nthreads = std::min<size_t>(nthreads, (size_t) std::atoi(e));
+	nthreads = std::min<size_t>(nthreads, std::min<size_t>(rows, 64));
+	std::atomic<size_t> next{0};
+	auto worker = [&]() {
+		for (size_t r = next++; r < rows; r = next++) {
+			const unsigned pix = (unsigned) (r / aa);
+			const int aax = (int) (r % aa);
+			const unsigned x = x0 + pix % nx, y = y0 + pix / nx;
+			float* o = out + r * aa * 3;
+			for (int aay = 0; aay < (int) aa; ++aay) {
+				Color c = R.trace(primary_ray(cb, w, h, x, y, aax, aay, aa_unit));
+				*o++ = c.r; *o++ = c.g; *o++ = c.b;
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (size_t i = 1; i < nthreads; ++i) pool.emplace_back(worker);
+	worker();
+	for (auto& t : pool) t.join();
 }
 
 // PpmWriter::save (ppmwriter.cpp:55-76): "P3 W H 255 \n", value + ' ', '\n' after every 19th.

@@ -134,8 +134,8 @@ struct PtxScene {
 	std::vector<void*> allocs;
 	WorkMem work;
 	std::vector<unsigned> tails;   // host copy of the tail counters a render reads back (sized once, at creation)
-	float* accum_copy = nullptr;   // the caller's accumulation buffer as it was before a render (scenes with two-child materials)
-	size_t accum_copy_floats = 0;
+	double* sums = nullptr;        // a render's own sums (see accumulate), folded into the caller's buffer at its end
+	size_t sums_len = 0;
 	Counters host_counters{};
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
@@ -733,7 +733,7 @@ void ptx_scene_destroy(PtxScene* scene) {
 	if (!scene) return;
 	(void) hipSetDevice(scene->device);
 	for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
-	if (scene->accum_copy) (void) hipFree(scene->accum_copy);
+	if (scene->sums) (void) hipFree(scene->sums);
 	for (void* p : scene->allocs) (void) hipFree(p);
 	delete scene;
 }
@@ -755,10 +755,10 @@ namespace {
 
 // One render into d_accum with the work memory `M` (the scene's own block, or any other that
 // holds the same parts).  Calls no allocating routine unless profiling has to create events
-// (may_create_events) or the straight way through the image needs its copy of the accumulation
-// buffer (allow_straight; see below).
+// (may_create_events) or the render keeps its sums in a buffer of the scene's (own_sums; see
+// accumulate in ptx_kernels.hpp), which grows with the largest image asked for.
 PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParams* rp, float* d_accum, hipStream_t stream, int check_overflow,
-                            PtxStats* stats, bool may_create_events, bool allow_straight) {
+                            PtxStats* stats, bool may_create_events, bool own_sums) {
 	BounceArgs A{};
 	A.S = sc->dev;
 	camera_basis(sc->camera, *rp, A.cam);
@@ -831,25 +831,26 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	//     rays a launch had to leave behind: a segment that holds more than `take` records - deep trees of
 	//     two-child materials only; a one-child material never hands on more rays than it took.  The kernel
 	//     that sees such a segment raises Counters::remainder, and the image is rendered again the careful
-	//     way, into the accumulation buffer as it was before (a copy taken first).
+	//     way (the sums of the discarded pass went into the render's own buffer, which is cleared).
 	//   careful: one queue per depth, the counts read back after every primary chunk, remainders traced
-	//     deepest depth first (below).  Also the only way with work memory the library does not own
-	//     (no room for the copy), and with the fused pipeline.
+	//     deepest depth first (below).  Also the only way where the render adds into the caller's buffer
+	//     directly, and with the fused pipeline.
 	const bool can_remain = sc->branching && max_depth > 0;
-	bool straight = staged && max_depth > 0 && allow_straight;
-	if (straight && can_remain) {
-		const size_t need = (size_t) rp->width * rp->height * 3;
-		if (sc->accum_copy_floats < need) {
-			if (sc->accum_copy) (void) hipFree(sc->accum_copy);
-			sc->accum_copy = nullptr;
-			sc->accum_copy_floats = 0;
-			if (hipMalloc(reinterpret_cast<void**>(&sc->accum_copy), need * sizeof(float)) == hipSuccess) sc->accum_copy_floats = need;
-			else {
-				(void) hipGetLastError();
-				straight = false;  // no room for the copy: the careful way needs none
-			}
+	const bool straight = staged && max_depth > 0 && own_sums;
+	// the render's own sums (doubles, see accumulate): wherever the library may hold memory of its own
+	const size_t n_sums = (size_t) rp->width * rp->height * 3;
+	A.accum64 = nullptr;
+	if (own_sums) {
+		if (sc->sums_len < n_sums) {
+			if (sc->sums) (void) hipFree(sc->sums);
+			sc->sums = nullptr;
+			sc->sums_len = 0;
+			hipError_t e = hipMalloc(reinterpret_cast<void**>(&sc->sums), n_sums * sizeof(double));
+			if (e != hipSuccess) return fail(PTX_ERR_NOMEM, std::string("the render's buffer of sums: ") + hipGetErrorString(e));
+			sc->sums_len = n_sums;
 		}
-		if (straight) HIP_TRY(hipMemcpyAsync(sc->accum_copy, d_accum, need * sizeof(float), hipMemcpyDeviceToDevice, stream));
+		A.accum64 = sc->sums;
+		HIP_TRY(hipMemsetAsync(sc->sums, 0, n_sums * sizeof(double), stream));
 	}
 	unsigned nqueues = 0, n_seg = 0, seg_cap = 0, take = 0, take0 = 0;
 	uint64_t capd = 0, chunk = 0;
@@ -1024,13 +1025,17 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		HIP_TRY(hipStreamSynchronize(stream));
 		chained = false;
 		if (left) {
-			HIP_TRY(hipMemcpyAsync(d_accum, sc->accum_copy, (size_t) rp->width * rp->height * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+			HIP_TRY(hipMemsetAsync(sc->sums, 0, n_sums * sizeof(double), stream));
 			HIP_TRY(hipMemsetAsync(M.counters, 0, kCounterBytes, stream));
 			HIP_TRY(hipMemsetAsync(M.stat, 0, kStatBytes, stream));
 			// (the launches of the discarded pass stay in `launches` and in the profiling events: they cost their time)
 			PtxStatus is = image(false);
 			if (is != PTX_OK) return is;
 		}
+	}
+	if (own_sums) {
+		const unsigned fold_grid = (unsigned) std::min<size_t>((n_sums + kBlock - 1) / kBlock, 8192);
+		hipLaunchKernelGGL(k_fold, dim3(fold_grid), dim3(kBlock), 0, stream, d_accum, sc->sums, n_sums);
 	}
 	HIP_TRY(hipGetLastError());
 	if (check_overflow || stats) {

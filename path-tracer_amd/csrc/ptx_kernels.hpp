@@ -1012,7 +1012,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 	        __int_as_float(__builtin_amdgcn_readlane(b, 32))) + __int_as_float(__builtin_amdgcn_readlane(b, 48));
 }
 
-__device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned pix, f3 v, bool has) {
+template <class AT>
+__device__ __forceinline__ void accumulate_into(AT* __restrict__ accum, unsigned pix, f3 v, bool has) {
 	const unsigned long long has_mask = __ballot(has);
 	if (has_mask == 0) return;
 	const unsigned lane = lane_id();
@@ -1023,7 +1024,7 @@ __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned p
 		const unsigned first_pix = __builtin_amdgcn_readlane(pix, __builtin_ctzll(has_mask));
 		if (__ballot(has && pix != first_pix) == 0) {
 			const float sx = wave_sum(v.x), sy = wave_sum(v.y), sz = wave_sum(v.z);
-			if (lane < 3) atomicAdd(accum + (size_t) first_pix * 3 + lane, lane == 0 ? sx : lane == 1 ? sy : sz);
+			if (lane < 3) atomicAdd(accum + (size_t) first_pix * 3 + lane, (AT) (lane == 0 ? sx : lane == 1 ? sy : sz));
 			return;
 		}
 	}
@@ -1049,10 +1050,10 @@ __device__ __forceinline__ void accumulate(float* __restrict__ accum, unsigned p
 	const float y1 = __shfl_up(v.y, 1), z2 = __shfl_up(v.z, 2);
 	const bool second = !head && lane >= 1 && (live_heads >> (lane - 1) & 1);
 	const bool third = !head && lane >= 2 && !(heads >> (lane - 1) & 1) && (live_heads >> (lane - 2) & 1);
-	float* p = accum + (size_t) pix * 3;
-	if (live || second || third) atomicAdd(p + (live ? 0 : second ? 1 : 2), live ? v.x : second ? y1 : z2);
-	if (live && run < 2) atomicAdd(p + 1, v.y);
-	if (live && run < 3) atomicAdd(p + 2, v.z);
+	AT* p = accum + (size_t) pix * 3;
+	if (live || second || third) atomicAdd(p + (live ? 0 : second ? 1 : 2), (AT) (live ? v.x : second ? y1 : z2));
+	if (live && run < 2) atomicAdd(p + 1, (AT) v.y);
+	if (live && run < 3) atomicAdd(p + 2, (AT) v.z);
 }
 
 // u / n and u % n for u < 2^31 with inv = 1.0 / n in double: the product is below the true
@@ -1122,8 +1123,9 @@ struct BounceArgs {
 	unsigned last_depth;       // depth == max_ray_bounces: shade locally only
 	unsigned all_children;     // also trace child rays of exactly zero weight (PTX_TRACE_ZERO_WEIGHT)
 	unsigned flag_remainder;   // depth > 0: count the waves whose segment holds more than the launch takes (nobody comes back for the rest)
-	float* accum;
-	Counters* counters;        // overflow flag only
+	float* accum;              // the caller's accumulation buffer (added to directly only when accum64 is NULL)
+	double* accum64;           // this render's own sums, folded into `accum` at its end
+	Counters* counters;        // overflow / remainder flags
 	unsigned long long* stat;  // work counters, spread over kStatWaves slots
 	// staged pipeline only
 	RayQueue shadow;           // a = (o.xyz, bits(pixel))  b = (contribution rgb, bits(light)); plane c unused (32 B per shadow ray)
@@ -1134,6 +1136,17 @@ struct BounceArgs {
 	                           // ray = the sample's index in the batch (depth 0) or the ray's slot in `in`
 	unsigned* hit_count;
 };
+
+// Where the sums of a render go.  A pixel of a 10 000-sample image receives some 10^5 additions; into a float that
+// has grown to 10^4 each of them rounds at 10^-3, and together they show at the 10^-5 level of the finished pixel.
+// A render therefore adds into a buffer of doubles of its own (BounceArgs::accum64, zero at its start), and the
+// caller's float buffer receives one addition per pixel at its end (k_fold).  The sums inside a wave stay float
+// (64 terms); the float buffer is added to directly only where the library may not hold memory of its own.
+template <class ARGS>
+__device__ __forceinline__ void accumulate(const ARGS& A, unsigned pix, f3 v, bool has) {
+	if (A.accum64) accumulate_into(A.accum64, pix, v, has);
+	else accumulate_into(A.accum, pix, v, has);
+}
 
 // Software pipelining of the queue kernels.  The memory counter of a wave (vmcnt) retires loads,
 // stores and atomics strictly in issue order, and the compiler, which cannot count the stores of
@@ -1296,7 +1309,7 @@ __global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) 
 			contrib = shade<INTPOW>(A.S, sf, h.id, w, A.last_depth != 0, A.all_children != 0, stk, refl, refr, cnt_shadow);
 			++cnt_hits;
 		}
-		accumulate(A.accum, pix, contrib, hit);
+		accumulate(A, pix, contrib, hit);
 		float4 r1[3], r2[3];
 		pack_child(refl, pix, r1);
 		pack_child(refr, pix, r2);
@@ -1619,7 +1632,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3)
 			A.shadow.a[j] = stage.shadow_a[i];
 			A.shadow.b[j] = stage.shadow_b[i];
 		}
-		accumulate(A.accum, pend_pix, pend_contrib, pend_hit);
+		accumulate(A, pend_pix, pend_contrib, pend_hit);
 		pend_children = pend_shadows = 0;
 		pend_hit = false;
 	};
@@ -1807,7 +1820,7 @@ __global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs 
 		PTX_ARGS_AGAIN(ka);
 		pipeline_wait();
 		const float4 a = next_a, b = next_b;
-		accumulate(A.accum, prev_pix, prev_c, prev_lit);
+		accumulate(A, prev_pix, prev_c, prev_lit);
 		fetch(k + 1 < steps ? k + 1 : k);
 		const bool active = k * 64 + lane < n;
 		// the light's position through scalar loads, light by light (a vector load here would make
@@ -1835,7 +1848,7 @@ __global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs 
 		prev_c = c;
 		prev_lit = lit;
 	}
-	accumulate(A.accum, prev_pix, prev_c, prev_lit);
+	accumulate(A, prev_pix, prev_c, prev_lit);
 	stat_add_tests(stat_slot(A, wave), 3 + kTestKinds, tc);
 #undef A
 }
@@ -1930,6 +1943,11 @@ __global__ __launch_bounds__(kBlock) void k_add(float* __restrict__ a, const flo
 		a4[i] = x;
 	}
 	for (size_t i = n4 * 4 + (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) a[i] += b[i];
+}
+
+// a[i] += (float) sums[i]: a render's own sums into the caller's accumulation buffer, one rounding per pixel and channel
+__global__ __launch_bounds__(kBlock) void k_fold(float* __restrict__ a, const double* __restrict__ sums, size_t n) {
+	for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) a[i] += (float) sums[i];
 }
 
 // framework/renderer.cpp:86-89, :286-291 and ppmwriter.cpp:36-43

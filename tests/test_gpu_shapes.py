@@ -396,4 +396,54 @@ def test_full_size_4k_configs(pt, port, scenes):
     # the rank's share is already the image to a few 1e-3: the 1080p image at 1024 spp, every second pixel of it, is the same view
     lo = ds.render_image(1920, 1080, 32, nb)["color"]
     assert float(np.abs(share[::2, ::2] - lo).mean()) < 5e-3
+    # two windows of the rank's share against the oracle's samples s0 .. s1 of the same pixels (glass box + mesh, wall)
+    so = scenes.oracle_scene("cornell_buster")
+    for x0, y0 in ((2360, 840), (600, 1600)):
+        assert_window_equals_oracle_samples(port, so, share, w, h, aa, nb, x0, y0, s0, s1)
+    ds.close()
+
+
+def assert_window_equals_oracle_samples(port, s, color, w, h, aa, nb, x0, y0, s0, s1, nx=4, ny=3):
+    """color[y0:y0+ny, x0:x0+nx] (the tone-mapped average of samples s0 .. s1 of every pixel) against the oracle's
+    colours of those very samples, to the image bar.  Two references: the exact average of the samples (float64),
+    and the average the reference's own loop forms - one fp32 accumulator per pixel, samples added in grid order
+    (renderer.cpp:74-86) - which at 10^4 samples carries the rounding of 10^4 additions; the device's sums (wave
+    reductions, then float atomics) must meet the bar against the exact average and stay within the reference's own
+    rounding of the reference's."""
+    sc = port.sample_colors(s, w, h, aa, nb, x0, y0, nx, ny)[:, :, s0:s1]      # (ny, nx, samples, 3), un-tone-mapped
+    n = s1 - s0
+    assert np.isfinite(sc).all()
+    mean = sc.astype(np.float64).sum(axis=2) / n
+    exact = (mean / (mean + 1)).astype(f32)                                    # tone_map_color, renderer.cpp:286-291
+    seq = np.cumsum(sc, axis=2, dtype=f32)[:, :, -1] * (f32(1.0) / f32(n))     # traced_color += ...; *= 1.0f / n
+    seq = (seq / (seq + f32(1.0))).astype(f32)
+    got = color[y0:y0 + ny, x0:x0 + nx]
+    rmse, mx = float(np.sqrt(np.mean((got.astype(np.float64) - exact) ** 2))), float(np.abs(got - exact).max())
+    ref_own = float(np.abs(seq.astype(np.float64) - exact).max())              # what the reference's summation order costs it
+    print(f"window ({x0},{y0}) {n} samples: device vs exact average rmse {rmse:.2e} max {mx:.2e}; reference's own sum vs exact max {ref_own:.2e};"
+          f" device vs reference's sum max {float(np.abs(got - seq).max()):.2e}")
+    assert rmse <= 1e-6 and mx <= 1e-5, (rmse, mx)
+    assert float(np.abs(got - seq).max()) <= 1e-5 + ref_own
+
+
+def test_ten_thousand_samples_per_pixel_against_the_oracle(pt, port, scenes):
+    """The target of the north star: cornell + buster_sword at 1920x1080 with aa_steps = 100 (10 000 samples per
+    pixel, 20.7 G samples), rendered in full; three windows (glass box in front of the mesh, a wall, the glass
+    sphere) against the oracle's 10 000 samples of each of their pixels.  What is pinned here is the fp32
+    accumulation: every pixel receives some 10^5 float additions in an order the reference does not have."""
+    w, h, aa, nb = 1920, 1080, 100, 5
+    ds = pt.DeviceScene(scenes.host_scene("cornell_buster"), 0, 32 << 30)
+    a = ds.render_image(w, h, aa, nb)
+    st = a["stats"]
+    assert st["samples"] == w * h * aa * aa == st["per_depth_rays"][0] == st["per_depth_hits"][0]
+    assert np.isfinite(a["color"]).all() and (a["color"].reshape(-1, 3).max(axis=1) > 0).all()
+    names = scenes.host_scene("cornell_buster").prim_names()
+    prim, _ = ds.primary_hits(w, h, 1, 0)
+    prim = prim.reshape(h, w)
+    s = scenes.oracle_scene("cornell_buster")
+    seen = set()
+    for x0, y0 in ((1180, 420), (300, 800), (760, 150)):
+        seen |= {names[i] for i in np.unique(prim[y0:y0 + 3, x0:x0 + 4]) if i >= 0}
+        assert_window_equals_oracle_samples(port, s, a["color"], w, h, aa, nb, x0, y0, 0, aa * aa)
+    assert {"box1", "ball1"} <= seen and len(seen) >= 3, seen
     ds.close()
