@@ -146,10 +146,12 @@ def cpu_baseline(args, scene_path):
             "cpu_share": os.environ.get("OMP_NUM_THREADS"), "port_value": port["value"], "port_cores": threads, "port_sample": port["sample"]}
 
 
-def measured_traffic(args, queue_gib, kernel):
-    """HBM bytes per launch of `kernel` from the committed counter passes (the newest
+def measured_counters(args, queue_gib, kernel):
+    """Per-launch counter figures of `kernel` from the committed counter passes (the newest
     profiles/*_hbm_traffic.json, written by scripts/pmc_summary.py --traffic), if they were taken
-    on this workload: same scene, size, spp, bounces and queue memory, hence the same launches."""
+    on this workload: same scene, size, spp, bounces and queue memory, hence the same launches.
+    Returns {'hbm_bytes': .., 'valu_active_inst': .., 'wave_time_waiting': ..} (a key is missing
+    when the record lacks that pass) or None."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_hbm_traffic.json")))
     for path in reversed(files):
@@ -170,8 +172,37 @@ def measured_traffic(args, queue_gib, kernel):
                 and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
         if rows:
             n = sum(r["launches"] for r in rows)
-            return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n
+            out = {"hbm_bytes": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n, "record": os.path.basename(path)}
+            if all("valu_active_inst_per_launch" in r for r in rows):
+                out["valu_active_inst"] = sum(r["valu_active_inst_per_launch"] * r["launches"] for r in rows) / n
+            if all("wave_time_waiting" in r for r in rows):
+                out["wave_time_waiting"] = sum(r["wave_time_waiting"] * r["launches"] for r in rows) / n
+            return out
     return None
+
+
+HBM_COPY_GBS = 6300.0      # what a streaming copy reaches on this chip (the microarchitecture guide's measured rate)
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
+def classify(avg_launch_s, counters):
+    """What bounds the dominant kernel, from its launch time (measured here) and the committed counters:
+    'issue' when the vector ALUs are busy most of the time (an instruction occupies a SIMD for four cycles),
+    'hbm' when its HBM traffic runs at most of the rate a copy reaches, else 'latency'.  Without counters
+    for this workload: None."""
+    if not counters:
+        return None, None, None
+    valu_busy = None
+    if "valu_active_inst" in counters:
+        valu_busy = counters["valu_active_inst"] * 4 / (avg_launch_s * CLOCK_HZ * SIMDS)
+    traffic_gbs = counters["hbm_bytes"] / avg_launch_s / 1e9
+    if valu_busy is not None and valu_busy >= 0.6:
+        bound = "issue"
+    elif traffic_gbs >= 0.6 * HBM_COPY_GBS:
+        bound = "hbm"
+    else:
+        bound = "latency"
+    return bound, valu_busy, traffic_gbs
 
 
 def kernel_table(stats, census, nb, staged):
@@ -343,8 +374,22 @@ def main():
             achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
             symbol = {"k_trace<true>": "k_trace<true, %s, NoCount>", "k_trace<false>": "k_trace<false, %s, NoCount>",
                       "k_shadow": "k_shadow<%s, NoCount>"}.get(dom)
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, queue_gib, dom),
+            avg_s = k["ms"] * 1e-3 / k["launches"]
+            counters = measured_counters(args, queue_gib, dom)
+            bound, valu_busy, traffic_gbs = classify(avg_s, counters)
+            # `achieved` / `frac`: the per-ray model's bytes against the HBM peak (the contract's figure); `traffic`:
+            # the bytes the memory really moved per launch (counter passes), with the same launch time as
+            # traffic_frac (of 8 TB/s) and achievable_frac (of the 6.3 TB/s a copy reaches); `bound` says which
+            # resource the counters show the kernel waiting for - "issue" = vector instruction issue, in which
+            # case the HBM fractions describe how little of the memory system the kernel needs, not a shortfall
+            out["roofline"] = {"bound": bound if bound else "hbm (by the model: no counter record for this workload)", "kernel": dom,
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": counters["hbm_bytes"] if counters else None,
+                               "traffic_frac": traffic_gbs / HBM_PEAK_GBS if counters else None,
+                               "achievable_frac": traffic_gbs / HBM_COPY_GBS if counters else None,
+                               "traffic_over_algorithmic": counters["hbm_bytes"] / (k["bytes"] / k["launches"]) if counters else None,
+                               "valu_busy": valu_busy, "wave_time_waiting": counters.get("wave_time_waiting") if counters else None,
+                               "counter_record": counters.get("record") if counters else None,
                                "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
                                "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
                                "valu": None if k["flops"] is None else {
@@ -374,23 +419,39 @@ def main():
             out["verify_max_abs_vs_single_rank"] = float((col1 - color).abs().max().item())
         if args.save_ppm:
             pt.write_ppm(args.save_ppm, rgb.cpu().numpy().reshape(h, w, 3))
-        if world == 1 and not args.no_also and args.scene != "example.sdf":
-            # BASELINE configs[1] at its full size, one image through the same calls
-            hs2 = pt.HostScene(os.path.join(pt.SDF_DIR, "example.sdf"))
+        if world == 1 and not args.no_also and args.scene == "cornell_buster.sdf":
+            # one image each, through the same calls, of BASELINE configs[1] at its full size (example.sdf) and of the
+            # bench scene seen from close to the mesh (buster_closeup.sdf: the sword fills 70 % of the frame, so the
+            # primary closest-hit kernel is bound by the mesh walks, which the bench view barely touches)
             ds.close()
-            ds2 = pt.DeviceScene(hs2, device_index, queue_bytes)
-            rp2 = pt.render_params(w, h, aa, nb)
-            for k in range(2):
-                accum.zero_()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                ds2.render_accumulate(rp2, accum.data_ptr(), stream, check_overflow=True)
-                ds2.resolve(accum.data_ptr(), w, h, spp, color.data_ptr(), rgb.data_ptr(), stream)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-            out["also"] = {f"example.sdf {w}x{h}, aa_steps={aa}, max_ray_bounces={nb}": {"Msamples/s": samples_per_step / dt / 1e6, "ms_per_step": dt * 1e3}}
-            ds2.close()
             ds = None
+            out["also"] = {}
+            for other in ("example.sdf", "buster_closeup.sdf"):
+                ds2 = pt.DeviceScene(pt.HostScene(os.path.join(pt.SDF_DIR, other)), device_index, queue_bytes)
+                ds2.set_profiling(1)
+                rp2 = pt.render_params(w, h, aa, nb)
+                for k in range(2):
+                    accum.zero_()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    st2 = ds2.render_accumulate(rp2, accum.data_ptr(), stream, check_overflow=True, want_stats=True)
+                    ds2.resolve(accum.data_ptr(), w, h, spp, color.data_ptr(), rgb.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                row = {"Msamples/s": samples_per_step / dt / 1e6, "ms_per_step": dt * 1e3, "rays_per_sample": (st2["trace_rays"] + st2["shadow_rays"]) / st2["samples"],
+                       "kernel_ms": {"k_trace<true>": round(st2["kernel_ms"][0][0], 2), "k_trace<false>": round(sum(st2["kernel_ms"][0][1: nb + 1]), 2),
+                                     "k_shade": round(sum(st2["kernel_ms"][1][: nb + 1]), 2), "k_shadow": round(sum(st2["kernel_ms"][2][: nb + 1]), 2)}}
+                if other == "buster_closeup.sdf" and not args.no_census:
+                    ds2.set_profiling(2)
+                    accum.zero_()
+                    c = ds2.render_accumulate(rp2, accum.data_ptr(), stream, check_overflow=True, want_stats=True)
+                    names = ("slab", "triangle", "sphere", "box", "transform")
+                    r0 = max(c["per_depth_rays"][0], 1)
+                    row["tests_per_primary_ray"] = {n: c["trace_tests"][0][k] / r0 for k, n in enumerate(names)}
+                    # of a primary ray's slab tests, 10 are the room (its bounds, 8 leaf filters, the mesh's bounds): the rest are BVH nodes, two per visit
+                    row["bvh_node_visits_per_primary_ray"] = max(0.0, (c["trace_tests"][0][0] / r0 - 10.0) / 2.0)
+                out["also"][f"{other} {w}x{h}, aa_steps={aa}, max_ray_bounces={nb}"] = row
+                ds2.close()
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, scene_path)
         else:

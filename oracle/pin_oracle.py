@@ -22,6 +22,7 @@ SCENES = [
     ("example_fixed.sdf", 240, 135, 2, 5),
     ("cornell_buster.sdf", 160, 90, 1, 5),
     ("superhot_colored.sdf", 160, 90, 1, 5),
+    ("buster_closeup.sdf", 120, 68, 1, 5),
 ]
 
 

@@ -44,6 +44,12 @@ if len(sys.argv) > 2 and sys.argv[1] == '--traffic':
             if 'WRITE_SIZE' in v:
                 res[short(k)]['write_bytes_per_launch'] = v['WRITE_SIZE'] * 1024 / n
             res[short(k)]['launches'] = n
+            # issue counters of the same record (the SQ pass): bench.py turns them into the kernel's vector-ALU busy
+            # fraction with the launch time it measures itself
+            if 'SQ_ACTIVE_INST_VALU' in v:
+                res[short(k)]['valu_active_inst_per_launch'] = v['SQ_ACTIVE_INST_VALU'] / n
+            if 'SQ_WAIT_ANY' in v and v.get('SQ_WAVE_CYCLES'):
+                res[short(k)]['wave_time_waiting'] = v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES']
     for k, v in res.items():
         if 'fetch_bytes_per_launch' in v and 'write_bytes_per_launch' in v:
             v['hbm_bytes_per_launch'] = v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']

@@ -16,7 +16,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "oracle"))
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-SCENES = ["cornell", "example", "example_fixed", "cornell_buster", "superhot_colored"]
+SCENES = ["cornell", "example", "example_fixed", "cornell_buster", "superhot_colored", "buster_closeup"]
 
 
 def pytest_configure(config):
