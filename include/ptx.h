@@ -229,6 +229,9 @@ typedef struct PtxStats {
 	uint64_t trace_tests[16][5];
 	uint64_t shadow_tests[16][5];
 	uint64_t tests_counted;
+	/* chunks of primary samples that left rays behind on the straight way through (trees of two-child
+	 * materials deeper than the queues' headroom) and were rendered again the careful way */
+	uint64_t chunks_redone;
 } PtxStats;
 
 const char* ptx_last_error(void);
@@ -239,16 +242,21 @@ int ptx_device_count(void);
 
 /*
  * Validates and uploads a scene to `device`, builds the per-frame BVHs and allocates the
- * ray queues.  queue_bytes = HBM budget for the ray queues (0 = 8 GiB, or a third of the
+ * ray queues.  queue_bytes = HBM budget for the ray queues (0 = 32 GiB, or a third of the
  * memory the device has free at this moment if that is less; at least 96 MiB is taken; more
  * memory means fewer, larger kernel launches, never different results: 32 GiB is where the
- * gain ends, worth it for callers that render many images with one scene).
+ * gain ends, and the block costs the same few milliseconds to create and destroy at any size).
  * Replaces the per-thread Scene copies of framework/renderer.cpp:48.
  * A PtxScene owns its queues and counters: use it from one thread (one render) at a time;
  * different scenes are independent.  ptx_last_error() is per thread.
  */
 PtxStatus ptx_scene_create(const PtxSceneDesc* desc, int device, uint64_t queue_bytes, PtxScene** out);
+/* Releases the scene.  Its queue block is not returned to the device at once: the library keeps the largest
+ * block destroyed on each device for the next scene created there (a caller in the place of Renderer::render,
+ * framework/renderer.cpp:25-59, creates and destroys one scene per image, and releasing and mapping tens of
+ * GiB per image costs more than the image).  ptx_trim() returns the kept blocks. */
 void ptx_scene_destroy(PtxScene* scene);
+void ptx_trim(void);
 
 /*
  * Adds, for every pixel, the sum over the selected samples of trace(primary ray)

@@ -31,7 +31,7 @@ PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
     "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_write_ppm_binary", "ptx_write_pfm", "ptx_scene_info", "ptx_jitter",
     "ptx_scene_set_profiling", "ptx_render_accumulate_static", "ptx_render_image_multi", "ptx_write_image_async", "ptx_write_wait",
-    "ptx_accum_save", "ptx_accum_load",
+    "ptx_accum_save", "ptx_accum_load", "ptx_trim",
 ]
 
 
@@ -88,14 +88,14 @@ class PtxStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("trace_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
                 ("launches", C.c_uint64), ("per_depth_rays", C.c_uint64 * 16), ("per_depth_shadow", C.c_uint64 * 16),
                 ("per_depth_hits", C.c_uint64 * 16), ("kernel_ms", (C.c_double * 16) * 3), ("kernel_launches", (C.c_uint64 * 16) * 3),
-                ("trace_tests", (C.c_uint64 * 5) * 16), ("shadow_tests", (C.c_uint64 * 5) * 16), ("tests_counted", C.c_uint64)]
+                ("trace_tests", (C.c_uint64 * 5) * 16), ("shadow_tests", (C.c_uint64 * 5) * 16), ("tests_counted", C.c_uint64), ("chunks_redone", C.c_uint64)]
 
     def as_dict(self):
         return dict(samples=self.samples, trace_rays=self.trace_rays, shadow_rays=self.shadow_rays, shaded_hits=self.shaded_hits,
                     launches=self.launches, per_depth_rays=list(self.per_depth_rays), per_depth_shadow=list(self.per_depth_shadow),
                     per_depth_hits=list(self.per_depth_hits), kernel_ms=[list(r) for r in self.kernel_ms],
                     kernel_launches=[list(r) for r in self.kernel_launches], trace_tests=[list(r) for r in self.trace_tests],
-                    shadow_tests=[list(r) for r in self.shadow_tests], tests_counted=bool(self.tests_counted))
+                    shadow_tests=[list(r) for r in self.shadow_tests], tests_counted=bool(self.tests_counted), chunks_redone=self.chunks_redone)
 
 
 _libs = {}
@@ -153,6 +153,8 @@ def ptx_lib():
     L.ptx_write_ppm_binary.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.ptx_write_pfm.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
     L.ptx_jitter.restype = None
+    L.ptx_trim.restype = None
+    L.ptx_trim.argtypes = []
     L.ptx_jitter.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ptx_scene_set_profiling.argtypes = [vp, C.c_int]
     L.ptx_scene_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
@@ -472,3 +474,8 @@ def write_pfm(path, color):
 
 def device_count():
     return ptx_lib().ptx_device_count()
+
+
+def trim():
+    """ptx_trim: return the queue blocks the library kept from destroyed scenes to their devices."""
+    ptx_lib().ptx_trim()

@@ -127,15 +127,63 @@ static hipError_t scratch_on(int device, unsigned char** out) {
 	return hipSuccess;
 }
 
+// The queue block of the scene destroyed last on a device, kept for the next scene created there.  Mapping a block
+// of tens of GiB is quick as long as nothing has been written to it; releasing one a render has filled, and
+// mapping the next right after, took 0.6 to 1.6 s per call in a program that creates and destroys a scene per image
+// (32 GiB).  One block per device is held until ptx_trim() or the end of the process.
+struct KeptBlock {
+	void* p = nullptr;
+	uint64_t bytes = 0;
+};
+static std::mutex g_kept_mutex;
+static KeptBlock g_kept[kMaxDevices];
+
+// a block of at least `bytes` on `device` (the current device): the kept one if it is large enough and not more than
+// twice what is asked for, else a new one
+static hipError_t take_block(int device, uint64_t bytes, void** out, uint64_t* got) {
+	{
+		std::lock_guard<std::mutex> lock(g_kept_mutex);
+		if (device >= 0 && device < kMaxDevices) {
+			KeptBlock& k = g_kept[device];
+			if (k.p && k.bytes >= bytes && k.bytes <= 2 * bytes) {
+				*out = k.p;
+				*got = k.bytes;
+				k = KeptBlock{};
+				return hipSuccess;
+			}
+		}
+	}
+	*got = bytes;
+	return hipMalloc(out, bytes);
+}
+// gives a block back: it becomes the device's kept block unless that one is larger
+static void give_block(int device, void* p, uint64_t bytes) {
+	void* drop = p;
+	{
+		std::lock_guard<std::mutex> lock(g_kept_mutex);
+		if (device >= 0 && device < kMaxDevices && g_kept[device].bytes < bytes) {
+			drop = g_kept[device].p;
+			g_kept[device].p = p;
+			g_kept[device].bytes = bytes;
+		}
+	}
+	if (drop) (void) hipFree(drop);
+}
+
 struct PtxScene {
 	int device = 0;
 	DevScene dev{};
 	PtxCamera camera{};
 	std::vector<void*> allocs;
+	void* block = nullptr;   // the queue block (work.qmem), handed on to the device's next scene at destruction (give_block)
+	uint64_t block_bytes = 0;
 	WorkMem work;
 	std::vector<unsigned> tails;   // host copy of the tail counters a render reads back (sized once, at creation)
 	double* sums = nullptr;        // a render's own sums (see accumulate), folded into the caller's buffer at its end
 	size_t sums_len = 0;
+	void* undo = nullptr;          // one chunk's pixels of `sums` and the work counters as they were before the chunk (render_accumulate)
+	size_t undo_bytes = 0;
+	unsigned long long* host_word = nullptr;  // pinned: where the one word a chunk is checked by lands (a copy into pageable memory is staged and slow)
 	Counters host_counters{};
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
@@ -673,14 +721,13 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
 	if (queue_bytes == 0) {
-		// 8 GiB, or a third of what the device has free now if that is less.  Measured on the mesh scene at
-		// 1920x1080, 1024 spp: 8 GiB renders 12 % slower than 32 GiB (more, smaller launches; beyond 32 GiB nothing
-		// is gained), but a block of tens of GiB costs more to map and unmap than it saves on one image
-		// (about 4 ms per GiB to allocate and 23 ms per GiB to free): callers that render many images with
-		// one scene ask for 32 GiB, a one-image caller is better off with the default.
+		// 32 GiB, or a third of what the device has free now if that is less.  Measured on the mesh scene at
+		// 1920x1080, 1024 spp: 334 ms per image with 8 GiB, 314 with 16, 303 with 32, the same with 64 (more memory
+		// means fewer, larger launches); creating the scene takes 7 ms and destroying it 1 - 2 ms whatever the size
+		// (the block is mapped, not touched, until a render writes to it), so a one-image caller loses nothing.
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		queue_bytes = std::min<uint64_t>(free_b / 3, 8ull << 30);
+		queue_bytes = std::min<uint64_t>(free_b / 3, 32ull << 30);
 	}
 	uint64_t cap = queue_bytes / 48;
 	cap = std::min<uint64_t>(cap, 1ull << 33);  // 384 GiB: above any device; each queue is limited on its own (64 sub-queues of at most 2^25 records)
@@ -689,12 +736,12 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	sc->work.qslots = cap;
 	{
 		void* p = nullptr;
-		hipError_t e = hipMalloc(&p, cap * 48);
+		hipError_t e = take_block(device, cap * 48, &p, &sc->block_bytes);
 		if (e != hipSuccess) {
 			ptx_scene_destroy(sc.release());
 			return fail(PTX_ERR_NOMEM, std::string("ray queue allocation failed: ") + hipGetErrorString(e));
 		}
-		sc->allocs.push_back(p);
+		sc->block = p;
 		sc->device_bytes += cap * 48;
 		sc->work.qmem = static_cast<float4*>(p);
 	}
@@ -734,8 +781,23 @@ void ptx_scene_destroy(PtxScene* scene) {
 	(void) hipSetDevice(scene->device);
 	for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
 	if (scene->sums) (void) hipFree(scene->sums);
+	if (scene->undo) (void) hipFree(scene->undo);
+	if (scene->host_word) (void) hipHostFree(scene->host_word);
 	for (void* p : scene->allocs) (void) hipFree(p);
+	if (scene->block) give_block(scene->device, scene->block, scene->block_bytes);
 	delete scene;
+}
+
+void ptx_trim(void) {
+	for (int d = 0; d < kMaxDevices; ++d) {
+		KeptBlock k;
+		{
+			std::lock_guard<std::mutex> lock(g_kept_mutex);
+			k = g_kept[d];
+			g_kept[d] = KeptBlock{};
+		}
+		if (k.p && hipSetDevice(d) == hipSuccess) (void) hipFree(k.p);
+	}
 }
 
 PtxStatus ptx_scene_info(const PtxScene* sc, int32_t* n_frames, int32_t* n_prims, int32_t* n_bvh_nodes, int32_t* max_bvh_depth,
@@ -775,7 +837,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 
 	HIP_TRY(hipMemsetAsync(M.counters, 0, kCounterBytes, stream));
 	HIP_TRY(hipMemsetAsync(M.stat, 0, kStatBytes, stream));
-	uint64_t launches = 0;
+	uint64_t launches = 0, chunks_redone = 0;
 	const bool prof = sc->profiling > 0 && stats && may_create_events;
 	const bool count_tests = sc->profiling > 1 && stats;
 	// default: the staged pipeline; below some hundred thousand samples the fused one, whose one launch per depth
@@ -824,14 +886,15 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	// segment and nothing can overflow, whatever the materials do.
 	unsigned per_ray = sc->branching ? 2u : 1u;
 	if (staged) per_ray = std::max(per_ray, (unsigned) std::max(sc->dev.n_lights, 1));
-	// Two ways through the image.
-	//   straight: every depth of every primary chunk is launched once, back to back, and the host never looks
-	//     at a count.  Depth d reads the queue depth d-1 wrote and that queue is dead afterwards, so two ray
-	//     queues take turns and the memory goes into larger chunks.  What this cannot do is come back for the
-	//     rays a launch had to leave behind: a segment that holds more than `take` records - deep trees of
-	//     two-child materials only; a one-child material never hands on more rays than it took.  The kernel
-	//     that sees such a segment raises Counters::remainder, and the image is rendered again the careful
-	//     way (the sums of the discarded pass went into the render's own buffer, which is cleared).
+	// Two ways through a chunk of primary samples.
+	//   straight: every depth is launched once, back to back.  Depth d reads the queue depth d-1 wrote and that
+	//     queue is dead afterwards, so two ray queues take turns and the memory goes into larger chunks.  What
+	//     this cannot do is come back for the rays a launch had to leave behind: a segment that holds more than
+	//     `take` records - trees of two-child materials only; a one-child material never hands on more rays
+	//     than it took, and such scenes go through the whole image without the host looking at anything.  With
+	//     two-child materials the kernel that sees such a segment raises Counters::remainder; the host reads
+	//     that one word after every chunk, and if it is raised it puts back the chunk's pixels of the render's
+	//     sums (and the work counters) as they were before the chunk and renders the chunk again the careful way.
 	//   careful: one queue per depth, the counts read back after every primary chunk, remainders traced
 	//     deepest depth first (below).  Also the only way where the render adds into the caller's buffer
 	//     directly, and with the fused pipeline.
@@ -987,20 +1050,21 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		}
 		return PTX_OK;
 	};
-	auto image = [&](bool straight_way) -> PtxStatus {
-		two_queues = straight_way;
-		PtxStatus zs = size_queues(two_queues);
+	// primary samples [begin, end) of this render, chunk by chunk
+	auto careful_chunks = [&](uint64_t begin, uint64_t end) -> PtxStatus {
+		two_queues = false;
+		PtxStatus zs = size_queues(false);
 		if (zs != PTX_OK) return zs;
-		for (uint64_t first = 0; first < total; first += chunk) {
+		for (uint64_t first = begin; first < end; first += chunk) {
 			A.first_pix = (unsigned) (first / ns);
 			A.first_s = (unsigned) (first % ns);
-			A.batch = (unsigned) std::min<uint64_t>(chunk, total - first);
+			A.batch = (unsigned) std::min<uint64_t>(chunk, end - first);
 			for (unsigned d = 0; d <= max_depth; ++d) {
 				set_depth(d, 0, take);
 				PtxStatus ls = launch_depth(d);
 				if (ls != PTX_OK) return ls;
 			}
-			if (max_depth == 0 || straight_way) continue;
+			if (max_depth == 0) continue;
 			HIP_TRY(hipMemcpyAsync(tails, count_of(1), (size_t) max_depth * M.max_seg * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
 			HIP_TRY(hipStreamSynchronize(stream));
 			chained = false;
@@ -1014,24 +1078,63 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		}
 		return PTX_OK;
 	};
-	{
-		PtxStatus is = image(straight);
-		if (is != PTX_OK) return is;
-	}
-	if (straight && can_remain) {
-		// did any launch leave rays behind?  (one word, the only thing the host waits for)
-		unsigned long long left = 0;
-		HIP_TRY(hipMemcpyAsync(&left, &M.counters->remainder, sizeof left, hipMemcpyDeviceToHost, stream));
-		HIP_TRY(hipStreamSynchronize(stream));
-		chained = false;
-		if (left) {
-			HIP_TRY(hipMemsetAsync(sc->sums, 0, n_sums * sizeof(double), stream));
-			HIP_TRY(hipMemsetAsync(M.counters, 0, kCounterBytes, stream));
-			HIP_TRY(hipMemsetAsync(M.stat, 0, kStatBytes, stream));
-			// (the launches of the discarded pass stay in `launches` and in the profiling events: they cost their time)
-			PtxStatus is = image(false);
-			if (is != PTX_OK) return is;
+	auto straight_chunks = [&]() -> PtxStatus {
+		two_queues = true;
+		PtxStatus zs = size_queues(true);
+		if (zs != PTX_OK) return zs;
+		// what a chunk may have to put back: its pixels of the sums (a chunk is a run of consecutive pixels), the work counters
+		const uint64_t band_pixels = std::min<uint64_t>(chunk / ns + 2, (uint64_t) rp->width * rp->height);
+		if (can_remain) {
+			const size_t need = (size_t) band_pixels * 3 * sizeof(double) + (stats ? kStatBytes : 0);
+			if (sc->undo_bytes < need) {
+				if (sc->undo) (void) hipFree(sc->undo);
+				sc->undo = nullptr;
+				sc->undo_bytes = 0;
+				hipError_t e = hipMalloc(&sc->undo, need);
+				if (e != hipSuccess) return fail(PTX_ERR_NOMEM, std::string("the copy of a chunk's pixels: ") + hipGetErrorString(e));
+				sc->undo_bytes = need;
+			}
+			if (!sc->host_word) {
+				hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&sc->host_word), 64, hipHostMallocDefault);
+				if (e != hipSuccess) return fail(PTX_ERR_NOMEM, std::string("pinned word: ") + hipGetErrorString(e));
+			}
 		}
+		unsigned char* const undo_stat = static_cast<unsigned char*>(sc->undo) + (size_t) band_pixels * 3 * sizeof(double);
+		for (uint64_t first = 0; first < total; first += chunk) {
+			const uint64_t batch = std::min<uint64_t>(chunk, total - first);
+			const uint64_t p0 = first / ns, p1 = (first + batch - 1) / ns;  // the chunk's pixels, first and last
+			if (can_remain) {
+				HIP_TRY(hipMemcpyAsync(sc->undo, sc->sums + p0 * 3, (size_t) (p1 - p0 + 1) * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+				if (stats) HIP_TRY(hipMemcpyAsync(undo_stat, M.stat, kStatBytes, hipMemcpyDeviceToDevice, stream));
+			}
+			A.first_pix = (unsigned) p0;
+			A.first_s = (unsigned) (first % ns);
+			A.batch = (unsigned) batch;
+			for (unsigned d = 0; d <= max_depth; ++d) {
+				set_depth(d, 0, take);
+				PtxStatus ls = launch_depth(d);
+				if (ls != PTX_OK) return ls;
+			}
+			if (!can_remain) continue;
+			HIP_TRY(hipMemcpyAsync(sc->host_word, &M.counters->remainder, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			HIP_TRY(hipStreamSynchronize(stream));
+			chained = false;
+			if (!*sc->host_word) continue;
+			++chunks_redone;
+			HIP_TRY(hipMemcpyAsync(sc->sums + p0 * 3, sc->undo, (size_t) (p1 - p0 + 1) * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+			if (stats) HIP_TRY(hipMemcpyAsync(M.stat, undo_stat, kStatBytes, hipMemcpyDeviceToDevice, stream));
+			HIP_TRY(hipMemsetAsync(&M.counters->remainder, 0, sizeof(unsigned long long), stream));
+			// (the launches of the discarded pass stay in `launches` and in the profiling events: they cost their time)
+			PtxStatus cs = careful_chunks(first, first + batch);
+			if (cs != PTX_OK) return cs;
+			two_queues = true;
+			if ((zs = size_queues(true)) != PTX_OK) return zs;
+		}
+		return PTX_OK;
+	};
+	{
+		PtxStatus is = straight ? straight_chunks() : careful_chunks(0, total);
+		if (is != PTX_OK) return is;
 	}
 	if (own_sums) {
 		const unsigned fold_grid = (unsigned) std::min<size_t>((n_sums + kBlock - 1) / kBlock, 8192);
@@ -1050,6 +1153,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 			stats->shadow_rays = c.shadow_rays;
 			stats->shaded_hits = c.shaded_hits;
 			stats->launches = launches;
+			stats->chunks_redone = chunks_redone;
 			for (int k = 0; k < kMaxDepthSlots; ++k) {
 				stats->per_depth_rays[k] = c.per_depth[k];
 				stats->per_depth_shadow[k] = c.per_depth_shadow[k];
