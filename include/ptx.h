@@ -202,6 +202,9 @@ typedef enum PtxPipeline { PTX_PIPELINE_DEFAULT = 0, PTX_PIPELINE_FUSED = 1, PTX
  * the ray counts equal the reference's as well.
  */
 #define PTX_TRACE_ZERO_WEIGHT 0x100u
+/* or-ed into `pipeline` for ptx_render_image_multi: sum the per-GPU buffers with one RCCL reduce
+ * (ncclSum, ncclFloat, onto the first GPU) instead of the first GPU reading its peers' memory */
+#define PTX_REDUCE_RCCL 0x200u
 
 /* Work done by the last ptx_render_accumulate on this scene (whole call). */
 typedef struct PtxStats {
@@ -322,11 +325,25 @@ PtxStatus ptx_render_image(PtxScene* scene, const PtxRenderParams* params, float
  * own xGMI link and is added by a kernel), resolved there, and copied to the host arrays like
  * ptx_render_image does.  stats: n_scenes entries (one per worker) or NULL.  seconds: wall
  * time of the whole call.  Blocking; the workers' errors come back as this call's.
+ * The sum: by default one kernel on scenes[0]'s GPU that reads the peers' buffers in place
+ * (hipDeviceEnablePeerAccess; a peer it cannot map is copied over first); with PTX_REDUCE_RCCL in
+ * params->pipeline one RCCL reduce over communicators the library creates once per set of GPUs
+ * (librccl.so is looked up at run time; PTX_ERR_UNSUPPORTED without it).  Every scene keeps its
+ * buffers from call to call: no allocation per image after the first.
  * Processes that hold one GPU each (torch.distributed, MPI) use ptx_render_accumulate with
- * their own sample range and sum the buffers with one RCCL reduce instead.
+ * their own sample range and sum the buffers with one RCCL reduce of their own (ptx_reduce_accum).
  */
 PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, const PtxRenderParams* params, float* color,
                                  uint8_t* rgb8, double* seconds, PtxStats* stats);
+
+/*
+ * The one exchange of the multi-GPU render (no counterpart in the reference, which is one process
+ * on one CPU): ncclReduce(sum, float) of `n_floats` accumulation-buffer values onto rank `root` of
+ * the caller's communicator (`comm` is an ncclComm_t), queued on `stream`; d_recv may be NULL or
+ * equal d_send (in place).  The RCCL library is looked up at run time (librccl.so.1):
+ * PTX_ERR_UNSUPPORTED when there is none.
+ */
+PtxStatus ptx_reduce_accum(void* comm, const float* d_send, float* d_recv, uint64_t n_floats, int root, void* stream);
 
 /*
  * scene.root->intersect(ray) for n rays (framework/renderer.cpp:109, shape.hpp:28).

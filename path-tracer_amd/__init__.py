@@ -31,7 +31,7 @@ PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_scene_create", "ptx_scene_destroy", "ptx_render_accumulate",
     "ptx_resolve", "ptx_render_image", "ptx_intersect", "ptx_primary_hits", "ptx_write_ppm", "ptx_write_ppm_binary", "ptx_write_pfm", "ptx_scene_info", "ptx_jitter",
     "ptx_scene_set_profiling", "ptx_render_accumulate_static", "ptx_render_image_multi", "ptx_write_image_async", "ptx_write_wait",
-    "ptx_accum_save", "ptx_accum_load", "ptx_trim",
+    "ptx_accum_save", "ptx_accum_load", "ptx_trim", "ptx_reduce_accum",
 ]
 
 
@@ -155,6 +155,7 @@ def ptx_lib():
     L.ptx_jitter.restype = None
     L.ptx_trim.restype = None
     L.ptx_trim.argtypes = []
+    L.ptx_reduce_accum.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, vp]
     L.ptx_jitter.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ptx_scene_set_profiling.argtypes = [vp, C.c_int]
     L.ptx_scene_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
@@ -187,6 +188,7 @@ def host_lib():
     H.pth_renderer_options.restype = None
     H.pth_renderer_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     H.pth_renderer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    H.pth_select_devices.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     H.pth_shape_matrices.restype = None
     H.pth_shape_matrices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     H._typed = True
@@ -256,6 +258,7 @@ PIPELINES = {"default": 0, "fused": 1, "staged": 2}
 
 
 TRACE_ZERO_WEIGHT = 0x100
+REDUCE_RCCL = 0x200
 
 
 def render_params(width, height, aa_steps, max_ray_bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0, zero_weight=False):
@@ -313,8 +316,17 @@ class HostScene:
         return color, sec.value
 
 
+def select_devices(first_device, n_devices, visible, samples):
+    """Renderer::select_devices: (first, count) of the GPUs a selection comes to, or None if they are not there."""
+    a, b = C.c_int(0), C.c_int(0)
+    if host_lib().pth_select_devices(first_device, n_devices, visible, samples, C.byref(a), C.byref(b)) != 0:
+        return None
+    return a.value, b.value
+
+
 class HostRenderer:
-    """The host-side C++ Renderer (the reference's class, rendering on the GPUs) kept across calls."""
+    """The host-side C++ Renderer (the reference's class, rendering on the GPUs) kept across calls.
+    first_device < 0: the default, one GPU (the first); else n_devices GPUs from first_device on (0 = all from there on)."""
 
     def __init__(self, w, h, aa, bounces, ppm_path=None, first_device=-1, n_devices=0, keep_scene=False):
         self._H = host_lib()
@@ -416,10 +428,13 @@ class DeviceScene:
 IMAGE_FORMATS = {"ppm": 0, "ppm_binary": 1, "pfm": 2}
 
 
-def render_image_multi(scenes, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0):
-    """ptx_render_image_multi over a list of DeviceScene objects (one per GPU)."""
+def render_image_multi(scenes, w, h, aa, bounces, sample_begin=0, sample_end=None, pipeline="default", jitter_seed=0, rccl=False):
+    """ptx_render_image_multi over a list of DeviceScene objects (one per GPU).  rccl: sum the buffers with one RCCL
+    reduce (PTX_REDUCE_RCCL) instead of the first GPU reading its peers' memory."""
     L = ptx_lib()
     rp = render_params(w, h, aa, bounces, sample_begin, sample_end, pipeline, jitter_seed)
+    if rccl:
+        rp.pipeline |= REDUCE_RCCL
     color = np.zeros((h, w, 3), np.float32)
     rgb = np.zeros((h, w, 3), np.uint8)
     sec = C.c_double(0)
@@ -479,3 +494,9 @@ def device_count():
 def trim():
     """ptx_trim: return the queue blocks the library kept from destroyed scenes to their devices."""
     ptx_lib().ptx_trim()
+
+
+def reduce_accum(comm, d_send_ptr, d_recv_ptr, n_floats, root=0, stream=None):
+    """ptx_reduce_accum: one RCCL sum-reduce of an accumulation buffer onto rank `root` of the communicator `comm`
+    (an ncclComm_t as an integer / c_void_p)."""
+    _check(ptx_lib().ptx_reduce_accum(C.c_void_p(comm), C.c_void_p(d_send_ptr), C.c_void_p(d_recv_ptr or 0), n_floats, root, C.c_void_p(stream or 0)))

@@ -100,14 +100,15 @@ void* pth_renderer_create(unsigned w, unsigned hgt, unsigned aa, unsigned bounce
 	return r;
 }
 void pth_renderer_destroy(void* r) { delete static_cast<Renderer*>(r); }
-// first_device < 0: leave the GPU selection alone; n_devices 0 = all from first_device on
+// first_device < 0: leave the GPU selection alone (one GPU, the first); n_devices 0 = all from first_device on
 void pth_renderer_options(void* r, int first_device, int n_devices, int keep_scene) {
 	auto* R = static_cast<Renderer*>(r);
-	if (first_device >= 0) {
-		if (n_devices == 1) R->set_device(first_device);
-		else R->set_devices(n_devices);
-	}
+	if (first_device >= 0) R->set_devices(first_device, n_devices);
 	R->keep_scene(keep_scene != 0);
+}
+// Renderer::select_devices: the GPUs a selection comes to (no GPU needed to ask)
+int pth_select_devices(int first_device, int n_devices, int visible, unsigned long long samples, int* out_first, int* out_count) {
+	return Renderer::select_devices(first_device, n_devices, visible, samples, out_first, out_count) ? 0 : -1;
 }
 int pth_renderer_render(void* r, void* h, float* color, double* device_seconds, double* setup_seconds) {
 	auto* R = static_cast<Renderer*>(r);

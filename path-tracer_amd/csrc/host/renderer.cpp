@@ -4,6 +4,7 @@
 #include <chrono>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 #include "flatten.hpp"
 
@@ -43,8 +44,44 @@ Renderer::~Renderer() { drop_scene(); }
 void Renderer::drop_scene() {
 	for (PtxScene* s : dev_scenes_) ptx_scene_destroy(s);
 	dev_scenes_.clear();
-	kept_root_ = nullptr;
+	kept_root_.reset();
+	kept_print_ = 0;
 }
+
+bool Renderer::select_devices(int first, int n, int visible, unsigned long long samples, int* out_first, int* count) {
+	if (visible < 1 || first < 0 || first >= visible || n < 0) return false;
+	int k = n == 0 ? visible - first : n;
+	if (first + k > visible) return false;
+	if (samples < (unsigned long long) k) k = (int) (samples < 1 ? 1 : samples);  // every GPU renders at least one sample of every pixel
+	*out_first = first;
+	*count = k;
+	return true;
+}
+
+namespace {
+// FNV-1a over the values render() reads outside the shape tree: a camera moved or a light changed between two
+// render() calls of a kept scene must not be answered from the copy on the GPUs
+unsigned long long fingerprint(Scene const& scene) {
+	unsigned long long h = 1469598103934665603ull;
+	auto mix = [&](const void* p, size_t n) {
+		const unsigned char* b = static_cast<const unsigned char*>(p);
+		for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+	};
+	auto mixf = [&](float v) { mix(&v, sizeof v); };
+	auto mixc = [&](Color const& c) { mixf(c.r); mixf(c.g); mixf(c.b); };
+	auto mixv = [&](vec3 const& v) { mixf(v.x); mixf(v.y); mixf(v.z); };
+	mixf(scene.camera.fov_x); mixv(scene.camera.position); mixv(scene.camera.direction); mixv(scene.camera.up);
+	mixc(scene.ambient.intensity);
+	for (auto const& l : scene.lights) { mixv(l.position); mixc(l.intensity); }
+	for (auto const& [name, m] : scene.materials) {
+		mix(name.data(), name.size());
+		if (m) { mixc(m->ka); mixc(m->kd); mixc(m->ks); mixf(m->m); mixf(m->glossy); mixf(m->opacity); mixf(m->ior); }
+	}
+	const unsigned long long counts[2] = {scene.lights.size(), scene.materials.size()};
+	mix(counts, sizeof counts);
+	return h ? h : 1;
+}
+}  // namespace
 
 void Renderer::render(Scene const& scene) {
 	auto start = std::chrono::steady_clock::now();
@@ -54,7 +91,8 @@ void Renderer::render(Scene const& scene) {
 		throw static_cast<const char*>(error_.c_str());
 	};
 	setup_seconds_ = 0;
-	if (!(keep_ && kept_root_ == scene.root.get() && !dev_scenes_.empty())) {
+	const unsigned long long print = fingerprint(scene);
+	if (!(keep_ && !dev_scenes_.empty() && !kept_root_.expired() && kept_root_.lock() == scene.root && kept_print_ == print)) {
 		drop_scene();
 		FlatScene flat;
 		try {
@@ -64,16 +102,28 @@ void Renderer::render(Scene const& scene) {
 		}
 		const int visible = ptx_device_count();
 		if (visible < 1) raise("no gfx950 GPU: this Renderer has no CPU path");
-		int n = n_devices_ <= 0 ? visible - first_device_ : n_devices_;
-		if (first_device_ < 0 || first_device_ >= visible || n < 1 || first_device_ + n > visible) raise("the GPUs asked for are not there");
-		// every GPU renders at least one sample of every pixel
-		n = (int) std::min<unsigned long long>((unsigned long long) n, (unsigned long long) aa_steps_ * aa_steps_);
-		for (int k = 0; k < n; ++k) {
-			PtxScene* s = nullptr;
-			if (ptx_scene_create(&flat.desc, first_device_ + k, 0, &s) != PTX_OK) raise(ptx_last_error());
-			dev_scenes_.push_back(s);
+		int first = 0, n = 0;
+		if (!select_devices(first_device_, n_devices_, visible, (unsigned long long) aa_steps_ * aa_steps_, &first, &n)) raise("the GPUs asked for are not there");
+		// one copy of the scene per GPU, created side by side (BVH build and upload of one do not wait for the other's)
+		dev_scenes_.assign((size_t) n, nullptr);
+		std::vector<std::string> errors((size_t) n);
+		auto create = [&](int k) {
+			if (ptx_scene_create(&flat.desc, first + k, 0, &dev_scenes_[(size_t) k]) != PTX_OK) errors[(size_t) k] = ptx_last_error();
+		};
+		{
+			std::vector<std::thread> threads;
+			for (int k = 1; k < n; ++k) threads.emplace_back(create, k);
+			create(0);
+			for (auto& t : threads) t.join();
 		}
-		kept_root_ = scene.root.get();
+		for (int k = 0; k < n; ++k)
+			if (!dev_scenes_[(size_t) k]) {
+				const std::string msg = "GPU " + std::to_string(first + k) + ": " + errors[(size_t) k];
+				dev_scenes_.erase(std::remove(dev_scenes_.begin(), dev_scenes_.end(), nullptr), dev_scenes_.end());
+				raise(msg);
+			}
+		kept_root_ = scene.root;
+		kept_print_ = print;
 		setup_seconds_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 	}
 	PtxRenderParams rp{};
@@ -88,13 +138,24 @@ void Renderer::render(Scene const& scene) {
 	std::vector<PtxStats> per_gpu(dev_scenes_.size());
 	if (ptx_render_image_multi(dev_scenes_.data(), (int32_t) dev_scenes_.size(), &rp, color.data(), rows.data(), &device_seconds_, per_gpu.data()) != PTX_OK)
 		raise(ptx_last_error());
-	stats_ = per_gpu[0];  // the work of all GPUs together (times: the first GPU's)
+	stats_ = per_gpu[0];  // the work of all GPUs together; kernel_ms and kernel_launches stay the first GPU's (the GPUs run side by side)
 	for (size_t k = 1; k < per_gpu.size(); ++k) {
-		stats_.samples += per_gpu[k].samples;
-		stats_.trace_rays += per_gpu[k].trace_rays;
-		stats_.shadow_rays += per_gpu[k].shadow_rays;
-		stats_.shaded_hits += per_gpu[k].shaded_hits;
-		stats_.launches += per_gpu[k].launches;
+		PtxStats const& g = per_gpu[k];
+		stats_.samples += g.samples;
+		stats_.trace_rays += g.trace_rays;
+		stats_.shadow_rays += g.shadow_rays;
+		stats_.shaded_hits += g.shaded_hits;
+		stats_.launches += g.launches;
+		stats_.chunks_redone += g.chunks_redone;
+		for (int d = 0; d < 16; ++d) {
+			stats_.per_depth_rays[d] += g.per_depth_rays[d];
+			stats_.per_depth_shadow[d] += g.per_depth_shadow[d];
+			stats_.per_depth_hits[d] += g.per_depth_hits[d];
+			for (int j = 0; j < 5; ++j) {
+				stats_.trace_tests[d][j] += g.trace_tests[d][j];
+				stats_.shadow_tests[d][j] += g.shadow_tests[d][j];
+			}
+		}
 	}
 	if (!keep_) drop_scene();
 	for (size_t i = 0; i < color_buffer_.size(); ++i) color_buffer_[i] = Color{color[3 * i], color[3 * i + 1], color[3 * i + 2]};

@@ -23,6 +23,8 @@
 // Ray counts stay in device memory: every launch is a persistent grid that strides over the
 // count it reads; the host looks at the counters once per chunk of primary samples.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time (rccl())
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -184,6 +186,17 @@ struct PtxScene {
 	void* undo = nullptr;          // one chunk's pixels of `sums` and the work counters as they were before the chunk (render_accumulate)
 	size_t undo_bytes = 0;
 	unsigned long long* host_word = nullptr;  // pinned: where the one word a chunk is checked by lands (a copy into pageable memory is staged and slow)
+	// buffers of ptx_render_image_multi, kept from call to call: this worker's accumulation buffer; its copy on
+	// another GPU that cannot read it in place (multi_stage_device); colour and 8-bit rows of the first worker
+	float* multi_accum = nullptr;
+	size_t multi_accum_bytes = 0;
+	float* multi_stage = nullptr;
+	size_t multi_stage_bytes = 0;
+	int multi_stage_device = -1;
+	float* multi_color = nullptr;
+	size_t multi_color_bytes = 0;
+	uint8_t* multi_rgb = nullptr;
+	size_t multi_rgb_bytes = 0;
 	Counters host_counters{};
 	bool branching = false;  // some material spawns two children per hit
 	bool bouncing = false;   // some material spawns any child
@@ -296,7 +309,7 @@ PtxStatus check_params(const PtxRenderParams* p) {
 	if (p->sample_begin > p->sample_end || p->sample_end > p->aa_steps * p->aa_steps)
 		return fail(PTX_ERR_INVALID, "sample range outside [0, aa_steps^2]");
 	if (p->max_ray_bounces > kMaxBounces) return fail(PTX_ERR_UNSUPPORTED, "max_ray_bounces must not exceed 63");
-	if ((p->pipeline & ~(uint32_t) PTX_TRACE_ZERO_WEIGHT) > PTX_PIPELINE_STAGED) return fail(PTX_ERR_INVALID, "unknown pipeline");
+	if ((p->pipeline & ~(uint32_t) (PTX_TRACE_ZERO_WEIGHT | PTX_REDUCE_RCCL)) > PTX_PIPELINE_STAGED) return fail(PTX_ERR_INVALID, "unknown pipeline");
 	return PTX_OK;
 }
 
@@ -783,6 +796,13 @@ void ptx_scene_destroy(PtxScene* scene) {
 	if (scene->sums) (void) hipFree(scene->sums);
 	if (scene->undo) (void) hipFree(scene->undo);
 	if (scene->host_word) (void) hipHostFree(scene->host_word);
+	if (scene->multi_accum) (void) hipFree(scene->multi_accum);
+	if (scene->multi_color) (void) hipFree(scene->multi_color);
+	if (scene->multi_rgb) (void) hipFree(scene->multi_rgb);
+	if (scene->multi_stage) {
+		if (hipSetDevice(scene->multi_stage_device) == hipSuccess) (void) hipFree(scene->multi_stage);
+		(void) hipSetDevice(scene->device);
+	}
 	for (void* p : scene->allocs) (void) hipFree(p);
 	if (scene->block) give_block(scene->device, scene->block, scene->block_bytes);
 	delete scene;
@@ -842,7 +862,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	const bool count_tests = sc->profiling > 1 && stats;
 	// default: the staged pipeline; below some hundred thousand samples the fused one, whose one launch per depth
 	// instead of three is what counts when a launch holds little work (0.53 against 0.71 ms for 96x64, 4 spp)
-	const uint32_t pipeline = rp->pipeline & ~(uint32_t) PTX_TRACE_ZERO_WEIGHT;
+	const uint32_t pipeline = rp->pipeline & ~(uint32_t) (PTX_TRACE_ZERO_WEIGHT | PTX_REDUCE_RCCL);
 	A.all_children = (rp->pipeline & PTX_TRACE_ZERO_WEIGHT) ? 1u : 0u;
 	const bool staged = pipeline == PTX_PIPELINE_STAGED || (pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17)) || sc->dev.n_guards != 0;
 	sc->event_tag.clear();
@@ -1567,15 +1587,112 @@ PtxStatus ptx_accum_load(const char* path, int device, float* d_accum, uint32_t 
 }
 
 // ---------------------------------------------------------------------------
+// RCCL, looked up when first asked for (the library does not link against it: a program that never sums buffers
+// across GPUs, or has no RCCL, loads and runs without)
+// ---------------------------------------------------------------------------
+namespace {
+struct Rccl {
+	void* lib = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	const char* (*GetErrorString)(ncclResult_t) = nullptr;
+	std::string why;  // why it is not there
+	bool ok = false;
+};
+Rccl& rccl() {
+	static Rccl R;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (R.lib) break;
+		}
+		if (!R.lib) {
+			R.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+			return;
+		}
+		auto sym = [&](const char* n) { return dlsym(R.lib, n); };
+		R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(sym("ncclCommInitAll"));
+		R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+		R.Reduce = reinterpret_cast<decltype(R.Reduce)>(sym("ncclReduce"));
+		R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(sym("ncclGroupStart"));
+		R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(sym("ncclGroupEnd"));
+		R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+		R.ok = R.CommInitAll && R.CommDestroy && R.Reduce && R.GroupStart && R.GroupEnd && R.GetErrorString;
+		if (!R.ok) R.why = "librccl.so lacks one of ncclCommInitAll / ncclCommDestroy / ncclReduce / ncclGroupStart / ncclGroupEnd / ncclGetErrorString";
+	});
+	return R;
+}
+// communicators of this process, one set per list of devices (created once: setting one up takes longer than an image)
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;
+
+// peer access from device `to` to the memory of device `from`: 1 enabled, 0 not possible (asked once per pair)
+std::mutex g_peer_mutex;
+signed char g_peer[kMaxDevices][kMaxDevices];
+bool g_peer_init = false;
+bool peer_readable(int to, int from) {  // `to` is the current device
+	if (to == from) return true;
+	if (to < 0 || from < 0 || to >= kMaxDevices || from >= kMaxDevices) return false;
+	std::lock_guard<std::mutex> lock(g_peer_mutex);
+	if (!g_peer_init) {
+		std::memset(g_peer, -1, sizeof g_peer);
+		g_peer_init = true;
+	}
+	if (g_peer[to][from] < 0) {
+		int can = 0;
+		bool ok = hipDeviceCanAccessPeer(&can, to, from) == hipSuccess && can;
+		if (ok) {
+			const hipError_t e = hipDeviceEnablePeerAccess(from, 0);
+			ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+			(void) hipGetLastError();
+		}
+		g_peer[to][from] = ok ? 1 : 0;
+	}
+	return g_peer[to][from] == 1;
+}
+}  // namespace
+
+PtxStatus ptx_reduce_accum(void* comm, const float* d_send, float* d_recv, uint64_t n_floats, int root, void* stream_) {
+	if (!comm || !d_send) return fail(PTX_ERR_INVALID, "comm / d_send is NULL");
+	Rccl& R = rccl();
+	if (!R.ok) return fail(PTX_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
+	const ncclResult_t r = R.Reduce(d_send, d_recv ? d_recv : const_cast<float*>(d_send), (size_t) n_floats, ncclFloat, ncclSum, root, static_cast<ncclComm_t>(comm),
+	                                static_cast<hipStream_t>(stream_));
+	if (r != ncclSuccess) return fail(PTX_ERR_DEVICE, std::string("ncclReduce: ") + R.GetErrorString(r));
+	return PTX_OK;
+}
+
+// ---------------------------------------------------------------------------
 // one image on several GPUs
 // ---------------------------------------------------------------------------
+namespace {
+// a buffer of a scene that ptx_render_image_multi keeps from call to call, grown when a larger image is asked for
+hipError_t grow(void** p, size_t* have, size_t need) {
+	if (*have >= need) return hipSuccess;
+	if (*p) (void) hipFree(*p);
+	*p = nullptr;
+	*have = 0;
+	const hipError_t e = hipMalloc(p, need);
+	if (e == hipSuccess) *have = need;
+	return e;
+}
+}  // namespace
+
 PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, const PtxRenderParams* rp, float* color, uint8_t* rgb8, double* seconds,
                                  PtxStats* stats) {
 	if (!scenes || n_scenes < 1) return fail(PTX_ERR_INVALID, "no scenes");
+	if (n_scenes > kMaxPeers + 1) return fail(PTX_ERR_INVALID, "more than " + std::to_string(kMaxPeers + 1) + " scenes");
+	bool distinct = true;
 	for (int i = 0; i < n_scenes; ++i) {
 		if (!scenes[i]) return fail(PTX_ERR_INVALID, "scene " + std::to_string(i) + " is NULL");
-		for (int j = 0; j < i; ++j)
+		for (int j = 0; j < i; ++j) {
 			if (scenes[j] == scenes[i]) return fail(PTX_ERR_INVALID, "the same scene object twice: every worker needs its own (ptx_scene_create once per GPU)");
+			if (scenes[j]->device == scenes[i]->device) distinct = false;
+		}
 	}
 	PtxStatus st = check_params(rp);
 	if (st != PTX_OK) return st;
@@ -1583,13 +1700,13 @@ PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, cons
 	const size_t n = (size_t) rp->width * rp->height * 3;
 	const uint32_t ns = rp->sample_end - rp->sample_begin;
 	struct Worker {
-		float* d_accum = nullptr;
 		PtxStatus status = PTX_OK;
 		std::string error;
 	};
 	std::vector<Worker> work((size_t) n_scenes);
 	// the reference's fan-out over CPU threads (framework/renderer.cpp:39-53), over GPUs: worker r
-	// renders all pixels for the r-th slice of the per-pixel samples into a buffer on its own GPU
+	// renders all pixels for the r-th slice of the per-pixel samples into a buffer on its own GPU (the
+	// scene's own, kept from call to call)
 	auto run = [&](int r) {
 		Worker& w = work[(size_t) r];
 		PtxScene* sc = scenes[r];
@@ -1598,16 +1715,17 @@ PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, cons
 			w.error = std::move(m);
 		};
 		hipError_t e = hipSetDevice(sc->device);
-		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&w.d_accum), n * sizeof(float));
-		if (e == hipSuccess) e = hipMemsetAsync(w.d_accum, 0, n * sizeof(float), nullptr);
+		if (e == hipSuccess) e = grow(reinterpret_cast<void**>(&sc->multi_accum), &sc->multi_accum_bytes, n * sizeof(float));
+		if (e == hipSuccess) e = hipMemsetAsync(sc->multi_accum, 0, n * sizeof(float), nullptr);
 		if (e != hipSuccess) return bad(PTX_ERR_DEVICE, std::string("worker set-up: ") + hipGetErrorString(e));
 		PtxRenderParams part = *rp;
+		part.pipeline = rp->pipeline & ~(uint32_t) PTX_REDUCE_RCCL;
 		part.sample_begin = rp->sample_begin + (uint32_t) ((uint64_t) ns * (uint64_t) r / (uint64_t) n_scenes);
 		part.sample_end = rp->sample_begin + (uint32_t) ((uint64_t) ns * (uint64_t) (r + 1) / (uint64_t) n_scenes);
 		PtxStats* ps = stats ? stats + r : nullptr;
 		if (ps) std::memset(ps, 0, sizeof *ps);
 		if (part.sample_begin < part.sample_end) {
-			PtxStatus rs = render_accumulate(sc, sc->work, &part, w.d_accum, nullptr, 1, ps, true, true);
+			PtxStatus rs = render_accumulate(sc, sc->work, &part, sc->multi_accum, nullptr, 1, ps, true, true);
 			if (rs != PTX_OK) return bad(rs, ptx_last_error());
 		}
 		e = hipStreamSynchronize(nullptr);
@@ -1619,77 +1737,81 @@ PtxStatus ptx_render_image_multi(PtxScene* const* scenes, int32_t n_scenes, cons
 		run(0);
 		for (auto& t : threads) t.join();
 	}
-	auto cleanup = [&]() {
-		for (int r = 0; r < n_scenes; ++r)
-			if (work[(size_t) r].d_accum) {
-				(void) hipSetDevice(scenes[r]->device);
-				(void) hipFree(work[(size_t) r].d_accum);
-			}
-	};
 	for (int r = 0; r < n_scenes; ++r)
-		if (work[(size_t) r].status != PTX_OK) {
-			const PtxStatus ws = work[(size_t) r].status;
-			const std::string msg = "GPU worker " + std::to_string(r) + ": " + work[(size_t) r].error;
-			cleanup();
-			return fail(ws, msg);
+		if (work[(size_t) r].status != PTX_OK) return fail(work[(size_t) r].status, "GPU worker " + std::to_string(r) + ": " + work[(size_t) r].error);
+	PtxScene* const s0 = scenes[0];
+	const int dev0 = s0->device;
+	HIP_TRY(hipSetDevice(dev0));
+	// ---- the sum of the buffers on the first scene's GPU
+	bool summed = n_scenes == 1;
+	if (!summed && (rp->pipeline & PTX_REDUCE_RCCL)) {
+		// one RCCL reduce (sum, float) onto the first GPU: one communicator per GPU of this process, the calls of all GPUs in one group
+		if (!distinct) return fail(PTX_ERR_INVALID, "PTX_REDUCE_RCCL needs every scene on a GPU of its own (RCCL refuses two ranks on one device)");
+		Rccl& R = rccl();
+		if (!R.ok) return fail(PTX_ERR_UNSUPPORTED, "RCCL is not available: " + R.why);
+		std::vector<int> devs;
+		for (int r = 0; r < n_scenes; ++r) devs.push_back(scenes[r]->device);
+		std::vector<ncclComm_t> comms;
+		{
+			std::lock_guard<std::mutex> lock(g_comm_mutex);
+			auto it = g_comms.find(devs);
+			if (it == g_comms.end()) {
+				std::vector<ncclComm_t> fresh((size_t) n_scenes, nullptr);
+				const ncclResult_t r = R.CommInitAll(fresh.data(), n_scenes, devs.data());
+				if (r != ncclSuccess) return fail(PTX_ERR_DEVICE, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
+				it = g_comms.emplace(devs, fresh).first;
+			}
+			comms = it->second;
 		}
-	// the sum of the buffers on the first scene's GPU: every other GPU's buffer comes over its own
-	// link (xGMI is point to point: the copies of different peers do not share a wire), each into a
-	// staging buffer of its own on a stream of its own, so that the copies run side by side; the
-	// additions follow on one stream in worker order (the sum does not depend on which copy ends
-	// first); 25 MB per peer at 1920x1080
-	const int dev0 = scenes[0]->device;
-	std::vector<float*> stage((size_t) n_scenes, nullptr);
-	std::vector<hipStream_t> copy_stream((size_t) n_scenes, nullptr);
-	std::vector<hipEvent_t> copied((size_t) n_scenes, nullptr);
-	float* d_color = nullptr;
-	uint8_t* d_rgb = nullptr;
-	auto cleanup0 = [&]() {
-		(void) hipSetDevice(dev0);
-		(void) hipDeviceSynchronize();
+		ncclResult_t r = R.GroupStart();
+		for (int k = 0; k < n_scenes && r == ncclSuccess; ++k) {
+			HIP_TRY(hipSetDevice(scenes[k]->device));
+			r = R.Reduce(scenes[k]->multi_accum, scenes[k]->multi_accum, n, ncclFloat, ncclSum, 0, comms[(size_t) k], nullptr);
+		}
+		const ncclResult_t ge = R.GroupEnd();
+		if (r == ncclSuccess) r = ge;
+		if (r != ncclSuccess) return fail(PTX_ERR_DEVICE, std::string("ncclReduce: ") + R.GetErrorString(r));
+		for (int k = 0; k < n_scenes; ++k) {
+			HIP_TRY(hipSetDevice(scenes[k]->device));
+			HIP_TRY(hipStreamSynchronize(nullptr));
+		}
+		HIP_TRY(hipSetDevice(dev0));
+		summed = true;
+	}
+	if (!summed) {
+		// One kernel on the first GPU reads every other GPU's buffer where it lies (xGMI is point to point: the reads
+		// of different peers travel over different links, side by side) and adds them in worker order.  A peer whose
+		// memory this GPU cannot map is copied into a staging buffer here first.
+		PeerList L{};
 		for (int r = 1; r < n_scenes; ++r) {
-			if (copied[(size_t) r]) (void) hipEventDestroy(copied[(size_t) r]);
-			if (copy_stream[(size_t) r]) (void) hipStreamDestroy(copy_stream[(size_t) r]);
-			if (stage[(size_t) r]) (void) hipFree(stage[(size_t) r]);
+			PtxScene* sr = scenes[r];
+			const float* src = sr->multi_accum;
+			if (!peer_readable(dev0, sr->device)) {
+				if (sr->multi_stage && sr->multi_stage_device != dev0) {  // (staged for another GPU before)
+					HIP_TRY(hipSetDevice(sr->multi_stage_device));
+					(void) hipFree(sr->multi_stage);
+					sr->multi_stage = nullptr;
+					sr->multi_stage_bytes = 0;
+					HIP_TRY(hipSetDevice(dev0));
+				}
+				HIP_TRY(grow(reinterpret_cast<void**>(&sr->multi_stage), &sr->multi_stage_bytes, n * sizeof(float)));
+				sr->multi_stage_device = dev0;
+				HIP_TRY(hipMemcpyPeerAsync(sr->multi_stage, dev0, sr->multi_accum, sr->device, n * sizeof(float), nullptr));
+				src = sr->multi_stage;
+			}
+			L.p[L.n++] = src;
 		}
-		if (d_color) (void) hipFree(d_color);
-		if (d_rgb) (void) hipFree(d_rgb);
-		cleanup();
-	};
-#define TRY_M(expr)                                                                         \
-	do {                                                                                    \
-		hipError_t e_ = (expr);                                                             \
-		if (e_ != hipSuccess) {                                                             \
-			cleanup0();                                                                     \
-			return fail(PTX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-		}                                                                                   \
-	} while (0)
-	TRY_M(hipSetDevice(dev0));
-	for (int r = 1; r < n_scenes; ++r) {
-		TRY_M(hipMalloc(reinterpret_cast<void**>(&stage[(size_t) r]), n * sizeof(float)));
-		TRY_M(hipStreamCreateWithFlags(&copy_stream[(size_t) r], hipStreamNonBlocking));
-		TRY_M(hipEventCreateWithFlags(&copied[(size_t) r], hipEventDisableTiming));
-		TRY_M(hipMemcpyPeerAsync(stage[(size_t) r], dev0, work[(size_t) r].d_accum, scenes[r]->device, n * sizeof(float), copy_stream[(size_t) r]));
-		TRY_M(hipEventRecord(copied[(size_t) r], copy_stream[(size_t) r]));
+		const unsigned grid = (unsigned) std::min<size_t>((n / 4 + kBlock - 1) / kBlock + 1, 8192);
+		hipLaunchKernelGGL(k_add_peers, dim3(grid), dim3(kBlock), 0, nullptr, s0->multi_accum, L, n);
+		HIP_TRY(hipGetLastError());
 	}
-	for (int r = 1; r < n_scenes; ++r) {
-		TRY_M(hipStreamWaitEvent(nullptr, copied[(size_t) r], 0));
-		const unsigned grid = (unsigned) std::min<size_t>((n / 4 + kBlock - 1) / kBlock + 1, 4096);
-		hipLaunchKernelGGL(k_add, dim3(grid), dim3(kBlock), 0, nullptr, work[0].d_accum, stage[(size_t) r], n);
-		TRY_M(hipGetLastError());
-	}
-	TRY_M(hipMalloc(reinterpret_cast<void**>(&d_color), n * sizeof(float)));
-	TRY_M(hipMalloc(reinterpret_cast<void**>(&d_rgb), n));
-	st = ptx_resolve(dev0, work[0].d_accum, rp->width, rp->height, ns ? ns : 1, d_color, d_rgb, nullptr);
-	if (st != PTX_OK) {
-		cleanup0();
-		return st;
-	}
-	if (color) TRY_M(hipMemcpy(color, d_color, n * sizeof(float), hipMemcpyDeviceToHost));
-	if (rgb8) TRY_M(hipMemcpy(rgb8, d_rgb, n, hipMemcpyDeviceToHost));
-	TRY_M(hipDeviceSynchronize());
-#undef TRY_M
-	cleanup0();
+	HIP_TRY(grow(reinterpret_cast<void**>(&s0->multi_color), &s0->multi_color_bytes, n * sizeof(float)));
+	HIP_TRY(grow(reinterpret_cast<void**>(&s0->multi_rgb), &s0->multi_rgb_bytes, n));
+	st = ptx_resolve(dev0, s0->multi_accum, rp->width, rp->height, ns ? ns : 1, s0->multi_color, s0->multi_rgb, nullptr);
+	if (st != PTX_OK) return st;
+	if (color) HIP_TRY(hipMemcpy(color, s0->multi_color, n * sizeof(float), hipMemcpyDeviceToHost));
+	if (rgb8) HIP_TRY(hipMemcpy(rgb8, s0->multi_rgb, n, hipMemcpyDeviceToHost));
+	HIP_TRY(hipDeviceSynchronize());
 	if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return PTX_OK;
 }

@@ -1928,21 +1928,31 @@ __global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
 	}
 }
 
-// a += b over n floats (the sum of the per-GPU accumulation buffers)
-__global__ __launch_bounds__(kBlock) void k_add(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+// a += b1 + b2 + ... over n floats, in that order: the sum of the per-GPU accumulation buffers, every peer's buffer read where it lies
+constexpr int kMaxPeers = 15;
+struct PeerList {
+	const float* p[kMaxPeers];
+	int n;
+};
+__global__ __launch_bounds__(kBlock) void k_add_peers(float* __restrict__ a, PeerList L, size_t n) {
 	const size_t n4 = n / 4;
 	float4* a4 = reinterpret_cast<float4*>(a);
-	const float4* b4 = reinterpret_cast<const float4*>(b);
 	for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t) gridDim.x * kBlock) {
 		float4 x = a4[i];
-		const float4 y = b4[i];
-		x.x += y.x;
-		x.y += y.y;
-		x.z += y.z;
-		x.w += y.w;
+		for (int k = 0; k < L.n; ++k) {
+			const float4 y = reinterpret_cast<const float4*>(L.p[k])[i];
+			x.x += y.x;
+			x.y += y.y;
+			x.z += y.z;
+			x.w += y.w;
+		}
 		a4[i] = x;
 	}
-	for (size_t i = n4 * 4 + (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) a[i] += b[i];
+	for (size_t i = n4 * 4 + (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) {
+		float x = a[i];
+		for (int k = 0; k < L.n; ++k) x += L.p[k][i];
+		a[i] = x;
+	}
 }
 
 // a[i] += (float) sums[i]: a render's own sums into the caller's accumulation buffer, one rounding per pixel and channel

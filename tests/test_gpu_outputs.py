@@ -44,6 +44,84 @@ def test_one_image_on_several_gpus(pt, scenes):
         d.close()
 
 
+def _rccl():
+    """the RCCL library this process already holds (torch brings one), or the system's"""
+    import ctypes
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            return ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            continue
+    return None
+
+
+def test_rccl_reduce_through_the_c_abi(pt):
+    """ptx_reduce_accum = ncclReduce(sum, float) through the library's run-time lookup of RCCL, on a communicator of
+    one rank (all this one-GPU box can hold: RCCL refuses two ranks on one device): the call resolves the library,
+    queues the reduce on the stream given and leaves the buffer as it was; with PTX_REDUCE_RCCL two workers on one
+    GPU are refused with a clear error."""
+    import ctypes
+    import torch
+    lib = _rccl()
+    if lib is None:
+        pytest.skip("no librccl.so on this machine")
+    comm = ctypes.c_void_p()
+    devs = (ctypes.c_int * 1)(0)
+    assert lib.ncclCommInitAll(ctypes.byref(comm), 1, devs) == 0
+    try:
+        x = torch.arange(100000, dtype=torch.float32, device="cuda:0") * 0.5
+        want = x.clone()
+        out = torch.zeros_like(x)
+        stream = torch.cuda.current_stream().cuda_stream
+        pt.reduce_accum(comm.value, x.data_ptr(), out.data_ptr(), x.numel(), 0, stream)
+        pt.reduce_accum(comm.value, x.data_ptr(), None, x.numel(), 0, stream)     # in place
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and torch.equal(x, want)
+        with pytest.raises(pt.PtxError):
+            pt.reduce_accum(None, x.data_ptr(), None, x.numel())
+    finally:
+        lib.ncclCommDestroy(comm)
+    hs = pt.HostScene(pt.SDF_DIR + "/cornell.sdf")
+    workers = [pt.DeviceScene(hs, 0, 1 << 27) for _ in range(2)]
+    with pytest.raises(pt.PtxError, match="GPU of its own"):
+        pt.render_image_multi(workers, 64, 48, 2, 3, rccl=True)
+    one = pt.render_image_multi(workers[:1], 64, 48, 2, 3, rccl=True)         # a single worker has nothing to sum
+    assert np.isfinite(one["color"]).all()
+    for d in workers:
+        d.close()
+
+
+def test_two_gpus_when_there_are_two(pt, scenes):
+    """On a machine with two GPUs or more: one image over two GPUs of this process, summed by peer reads and by one
+    RCCL reduce, and the two-rank bench (torch.distributed over the nccl backend = RCCL) with --verify.  Skipped
+    on a one-GPU box, where only the single-device halves of these paths can run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if pt.device_count() < 2:
+        pytest.skip("one GPU: the multi-GPU legs have no second device to run on")
+    hs = scenes.host_scene("cornell_buster")
+    w, h, aa, nb = 240, 135, 4, 5
+    one = scenes.device_scene("cornell_buster").render_image(w, h, aa, nb)
+    workers = [pt.DeviceScene(hs, d, 1 << 30) for d in (0, 1)]
+    for rccl in (False, True):
+        r = pt.render_image_multi(workers, w, h, aa, nb, rccl=rccl)
+        assert_image_close(r["color"], one["color"], r["rgb"], one["rgb"])
+        for k in ("samples", "trace_rays", "shadow_rays", "shaded_hits"):
+            assert sum(s[k] for s in r["stats"]) == one["stats"][k], k
+    for d in workers:
+        d.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PTX_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--aa", "8", "--cpu-seconds", "0",
+                          "--no-also", "--no-census", "--verify", "--queue-gib", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["verify_max_abs_vs_single_rank"] <= 1e-5
+
+
 def test_image_files_written_beside_the_rendering(pt, scenes, tmp_path):
     import torch
     g = load_golden("cornell")

@@ -196,3 +196,18 @@ def test_sample_range_partition(pt):
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_gpu_selection_arithmetic(pt):
+    """Renderer::select_devices (what set_device / set_devices come to), without a GPU: n GPUs from `first` on, 0 = all
+    from there on, never more GPUs than samples per pixel, None when the GPUs asked for are not there."""
+    sel = pt.select_devices
+    assert sel(0, 1, 8, 1024) == (0, 1)
+    assert sel(2, 0, 8, 1024) == (2, 6)        # all from GPU 2 on
+    assert sel(2, 4, 8, 1024) == (2, 4)        # (the selection used to fall back to GPU 0)
+    assert sel(0, 0, 8, 1024) == (0, 8)
+    assert sel(0, 0, 8, 4) == (0, 4)           # every GPU renders at least one sample of every pixel
+    assert sel(3, 0, 8, 1) == (3, 1)
+    assert sel(7, 1, 8, 16) == (7, 1)
+    assert sel(7, 2, 8, 16) is None
+    assert sel(8, 1, 8, 16) is None and sel(-1, 1, 8, 16) is None and sel(0, -2, 8, 16) is None and sel(0, 1, 0, 16) is None
