@@ -264,10 +264,14 @@ void ptx_trim(void);
 /*
  * Adds, for every pixel, the sum over the selected samples of trace(primary ray)
  * (framework/renderer.cpp:74-85) to d_accum (w*h*3 floats, row-major, y up, NOT cleared
- * here).  All device work goes to `stream`.  The call waits on that stream once per chunk of
- * primary samples when the scene spawns secondary rays (it reads the queue counters; a chunk
- * is as many samples as the queue memory is certain to hold the ray tree of), and once at the
- * end for the statistics when `stats` is non-NULL or check_overflow is non-zero.
+ * here).  All device work goes to `stream`.  The sums of one call are formed in doubles in a
+ * buffer of the scene's own (allocated at the first call, grown with the image size) and added to
+ * d_accum once per pixel at the end of the call.  Host waits on the stream: none while rendering
+ * when no material of the scene spawns two child rays; with such materials one per chunk of
+ * primary samples (one word is read back: whether a launch had to leave rays behind, in which
+ * case that chunk is rendered again with one queue per depth; a chunk is as many samples as the
+ * queue memory is certain to hold the ray tree of); and once at the end for the statistics when
+ * `stats` is non-NULL or check_overflow is non-zero.
  * Launches are sized so that no queue can fill up whatever the materials do; the kernels still
  * flag a record that would not fit, and with check_overflow != 0 (or stats) the call reads that
  * flag at its end and returns PTX_ERR_OVERFLOW if it was ever raised (check_overflow = 0 and
@@ -277,9 +281,10 @@ PtxStatus ptx_render_accumulate(PtxScene* scene, const PtxRenderParams* params, 
                                 int check_overflow, PtxStats* stats);
 
 /*
- * ptx_render_accumulate for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same arguments, same kernels, same results; the queues and counters live in a
+ * ptx_render_accumulate for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, code under HIP graph capture - see the host waits below).  No
+ * counterpart in the reference.  Same arguments, same kernels, same results (the sums go straight
+ * into d_accum as float atomics: there is no buffer of doubles to keep them in); the queues and counters live in a
  * 128 MiB array inside the library's code object (every GPU that runs the library holds its own
  * copy until the process ends; ptx_scene_create looks its address up once per device) instead of
  * the scene's own block, and the call allocates and frees nothing: no hipMalloc / hipFree, no
@@ -292,6 +297,11 @@ PtxStatus ptx_render_accumulate(PtxScene* scene, const PtxRenderParams* params, 
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two threads, two
  * streams, two scenes) race; run them one after the other.  What must start at zero is cleared
  * by the call itself.
+ * Host waits: with check_overflow = 0 and stats = NULL the call never waits on the stream when
+ * no material of the scene spawns two child rays - it then consists of memsets and kernel
+ * launches only and may be issued on a stream under capture (hipStreamBeginCapture); a scene with
+ * two-child materials makes it read the queue counters back once per chunk of primary samples,
+ * which a capturing stream refuses.
  */
 #define PTX_STATIC_MAX_SAMPLES (1u << 24)
 #define PTX_STATIC_MAX_BOUNCES 16u

@@ -919,7 +919,10 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	//     deepest depth first (below).  Also the only way where the render adds into the caller's buffer
 	//     directly, and with the fused pipeline.
 	const bool can_remain = sc->branching && max_depth > 0;
-	const bool straight = staged && max_depth > 0 && own_sums;
+	// (without two-child materials the straight way needs nothing put back, hence no memory of the library's own and
+	// no look at the device: with check_overflow = 0 and no statistics asked for such a render is launches and
+	// memsets only, which a stream under capture accepts)
+	const bool straight = max_depth > 0 && (!can_remain || (staged && own_sums));
 	// the render's own sums (doubles, see accumulate): wherever the library may hold memory of its own
 	const size_t n_sums = (size_t) rp->width * rp->height * 3;
 	A.accum64 = nullptr;

@@ -71,3 +71,51 @@ def test_static_work_memory_limits(pt, scenes):
     # exactly at the limit it runs: 4096 x 4096 x 1
     st = ds.render_accumulate(pt.render_params(4096, 4096, 1, 5), accum.data_ptr(), check_overflow=True, want_stats=True, static=True)
     assert st["samples"] == 1 << 24
+
+
+def test_static_call_under_graph_capture(pt, tmp_path):
+    """A scene without two-child materials (mirrors and diffuse surfaces: every hit hands on at most one ray) rendered
+    through the static entry point with check_overflow = 0 and no statistics is memsets and kernel launches only: the
+    call is issued on a stream under capture, the captured graph is launched twice, and each launch adds the image
+    the ordinary entry point gives."""
+    import ctypes
+    import torch
+    sdf = tmp_path / "mirrors.sdf"
+    sdf.write_text("define material mirror 0.1 0.1 0.1 0.2 0.2 0.2 0.9 0.9 0.9 20 1 1 1\n"
+                   "define material wall 0.3 0.3 0.3 0.6 0.5 0.4 0.2 0.2 0.2 8 0 1 1\n"
+                   "define shape box floor -6 -1 -14 6 0 2 wall\ndefine shape box back -6 0 -14 6 8 -13 wall\n"
+                   "define shape sphere ball -1.5 1.5 -8 1.5 mirror\ndefine shape box block 1 0 -9 3 2.5 -7 mirror\n"
+                   "define light bulb 0 7 -4 .8 .8 .8 20\ndefine ambient amb 1 1 1 0.5\n"
+                   "define camera eye 60.0 0 2.5 0 0 0 0\n")
+    ds = pt.DeviceScene(pt.HostScene(str(sdf)), 0, 1 << 28)
+    w, h, aa, nb = 160, 100, 2, 4
+    rp = pt.render_params(w, h, aa, nb, pipeline="staged")
+    want = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda:0")
+    st = ds.render_accumulate(rp, want.data_ptr(), None, check_overflow=True, want_stats=True)
+    assert st["per_depth_rays"][1] > 0 and st["shadow_rays"] > 0          # rays bounce and lights are asked for
+    ds.render_accumulate(rp, torch.zeros_like(want).data_ptr(), None, static=True)   # first use outside the capture
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    got = torch.zeros_like(want)
+    s = torch.cuda.Stream()
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    with torch.cuda.stream(s):
+        assert hip.hipStreamBeginCapture(ctypes.c_void_p(s.cuda_stream), 0) == 0       # hipStreamCaptureModeGlobal
+        try:
+            ds.render_accumulate(rp, got.data_ptr(), s.cuda_stream, check_overflow=False, want_stats=False, static=True)
+        finally:
+            rc = hip.hipStreamEndCapture(ctypes.c_void_p(s.cuda_stream), ctypes.byref(graph))
+        assert rc == 0 and graph.value
+        assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+        torch.cuda.synchronize()
+        assert float(got.abs().max()) == 0.0                                           # captured, not run
+        for _ in range(2):
+            assert hip.hipGraphLaunch(gexec, ctypes.c_void_p(s.cuda_stream)) == 0
+        s.synchronize()
+    hip.hipGraphExecDestroy(gexec)
+    hip.hipGraphDestroy(graph)
+    mean = (got / 2).cpu().numpy()
+    ref = want.cpu().numpy()
+    assert np.isfinite(mean).all() and ref.max() > 0
+    assert np.abs(mean - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))       # float atomics: the order of the sums differs
+    ds.close()
