@@ -299,6 +299,9 @@ void bounding_box(const PtxPrim& P, float4& lo, float4& hi) {
 	hi = make_float4(fh[0], fh[1], fh[2], 0.f);
 }
 
+#ifndef PTX_ROOT_BVH_LEAF
+#define PTX_ROOT_BVH_LEAF 1
+#endif
 constexpr int kRootBvhMin = 16;  // leaves of frame 0 from which they get a BVH of their own
 
 PtxStatus check_params(const PtxRenderParams* p) {
@@ -594,7 +597,11 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			finite = finite && std::isfinite(lo.x) && std::isfinite(lo.y) && std::isfinite(lo.z) && std::isfinite(hi.x) && std::isfinite(hi.y) && std::isfinite(hi.z);
 		}
 		if (finite) {
-			ptx::Bvh bvh = ptx::build_bvh(boxes);
+			// one shape per leaf: the box a ray must enter before a shape's exact test runs is then the shape's own, as in
+			// the list of a small frame 0 (a leaf of four shapes - spheres, boxes and triangles mixed - ran all four
+			// tests, each kind's code in turn, for every ray that touched their common box: 9 exact tests per shadow ray
+			// on a room with 54 shapes in it)
+			ptx::Bvh bvh = ptx::build_bvh(boxes, PTX_ROOT_BVH_LEAF);
 			if (bvh.max_depth > kStack) return fail(PTX_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
 			sc->max_depth = std::max(sc->max_depth, bvh.max_depth);
 			std::vector<DevRootPrim> rp(root_prims.size());

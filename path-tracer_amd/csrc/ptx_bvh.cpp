@@ -18,6 +18,7 @@ struct Item {
 struct Builder {
 	std::vector<Item> items;
 	Bvh out;
+	int max_leaf = kBvhMaxLeaf;
 
 	static Aabb empty_box() {
 		float inf = std::numeric_limits<float>::infinity();
@@ -59,7 +60,7 @@ struct Builder {
 	int32_t build(int b, int e, int depth) {
 		int n = e - b;
 		out.max_depth = std::max(out.max_depth, depth);
-		if (n <= kBvhMaxLeaf) return ~((b << 3) | (n - 1));
+		if (n <= max_leaf) return ~((b << 3) | (n - 1));
 
 		Aabb cb = empty_box();
 		for (int i = b; i < e; ++i)
@@ -68,7 +69,7 @@ struct Builder {
 				cb.hi[k] = std::max(cb.hi[k], items[i].c[k]);
 			}
 		int mid = -1;
-		bool force_median = depth + ceil_log2((n + kBvhMaxLeaf - 1) / kBvhMaxLeaf) + 2 >= kBvhMaxDepth;
+		bool force_median = depth + ceil_log2((n + max_leaf - 1) / max_leaf) + 2 >= kBvhMaxDepth;
 		if (!force_median) {
 			constexpr int NB = 16;
 			float best_cost = std::numeric_limits<float>::infinity();
@@ -149,8 +150,9 @@ struct Builder {
 
 }  // namespace
 
-Bvh build_bvh(std::vector<Aabb> const& boxes) {
+Bvh build_bvh(std::vector<Aabb> const& boxes, int max_leaf) {
 	Builder B;
+	B.max_leaf = std::min(std::max(max_leaf, 1), 8);
 	B.items.resize(boxes.size());
 	for (size_t i = 0; i < boxes.size(); ++i) {
 		B.items[i].box = boxes[i];

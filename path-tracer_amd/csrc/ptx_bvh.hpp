@@ -38,7 +38,7 @@ struct Bvh {
 constexpr int kBvhMaxLeaf = PTX_BVH_MAX_LEAF;
 constexpr int kBvhMaxDepth = 30;
 
-// boxes must be finite.  Deterministic (no threading, no RNG).
-Bvh build_bvh(std::vector<Aabb> const& boxes);
+// boxes must be finite.  Deterministic (no threading, no RNG).  max_leaf: most items per leaf (1 .. 8).
+Bvh build_bvh(std::vector<Aabb> const& boxes, int max_leaf = kBvhMaxLeaf);
 
 }  // namespace ptx

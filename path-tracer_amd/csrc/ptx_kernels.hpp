@@ -1563,7 +1563,10 @@ __device__ __forceinline__ void fill_shade_lds(ShadeLds<LT>& lds, const DevScene
 #define PTX_SHADE0_WAVES 4
 #endif
 template <bool PRIMARY, bool INTPOW, bool LT>
-__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : 3) void k_shade(BounceArgs A_) {
+#ifndef PTX_SHADE_GENERAL_WAVES
+#define PTX_SHADE_GENERAL_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (INTPOW ? 3 : PTX_SHADE_GENERAL_WAVES)) void k_shade(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
 	__shared__ ShadeLds<LT> lds;

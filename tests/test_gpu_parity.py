@@ -268,6 +268,28 @@ def test_general_specular_exponent_and_many_lights(pt, port, tmp_path):
             assert r["stats"]["shadow_rays"] > r["stats"]["shaded_hits"]   # more than one light per hit on average
 
 
+def test_many_shapes_fixture(pt, port):
+    """fixtures/sdf/many_shapes.sdf: 60 frame-0 leaves of all kinds under the reference's root (not yet split), 40
+    materials, two lights, specular exponents that are not whole numbers - the scene class that takes the shading
+    kernels without LDS tables and with the general pow, and the traversal kernels with a BVH over frame 0."""
+    from oracle_lib import random_rays
+    path = f"{pt.SDF_DIR}/many_shapes.sdf"
+    hs = pt.HostScene(path)
+    ds, s = pt.DeviceScene(hs, 0, 1 << 28), port.load(path)
+    o1, d1 = port.primary_rays(s, 160, 90, 1)
+    o2, d2 = random_rays(30000, 17, lo=(-8, -4, -29), hi=(8, 8, 3))
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, d), port.intersect(s, o, d)
+    assert np.array_equal(a["prim"], b["rank"]) and b["hit"].sum() > 40000
+    for k in ("t", "pos", "raydir", "normal"):
+        assert beq(a[k][b["hit"]], b[k][b["hit"]]), k
+    ref = port.render(s, 160, 90, 2, 5)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 90, 2, 5, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    ds.close()
+
+
 def test_full_size_properties(pt, scenes):
     """BASELINE config 2 at its full size (example.sdf 1920x1080, 1024 spp, 5 bounces), where
     the CPU oracle would take minutes: the two pipelines agree with each other to the image
