@@ -7,21 +7,24 @@
 //   for every chunk of primary samples (pixel-major, sample-minor, so the 64 lanes of a
 //   wave are 64 samples of ONE pixel), for every depth d of the ray tree:
 //     k_trace    closest hit of every ray of depth d (d = 0: rays generated in registers, no
-//                primary-ray queue; d > 0: read from queue[d-1]): frame-0 leaves in lock step
-//                (wave-uniform scalar loads, a bounding-box filter in front of each exact
-//                test) + one BVH2 walk per mesh frame with a per-lane stack in LDS; the hits
-//                are compacted into a list of 16-byte records
+//                primary-ray queue; d > 0: read from the queue depth d-1 wrote): frame-0 leaves in
+//                lock step (wave-uniform scalar loads, a bounding-box filter in front of each exact
+//                test; a BVH over them from 17 leaves on) + one BVH2 walk per mesh frame with a
+//                per-lane stack in LDS; the hits are compacted into a list of 16-byte records
 //     k_shade    one lane per hit: surface point, Phong terms, <= 2 weighted child rays
-//                (reflection / refraction) appended to queue[d], one shadow-ray record per
-//                light appended to the shadow queue, ambient term accumulated
+//                (reflection / refraction) appended to the next depth's queue, one shadow-ray record
+//                per light appended to the shadow queue, ambient term accumulated
 //     k_shadow   any-hit walk per shadow ray; an unblocked ray adds its contribution
 //     (or k_bounce: all of that in one kernel per depth, the fused pipeline)
-//     appends    one wave64 ballot + ONE returning atomic per wave and step
-//     accumulate segmented wave reduction per pixel, then one float atomicAdd per
-//                (pixel run, channel)
+//   Queues are cut into wave-private segments: wave w of every launch reads segment w of its input
+//   and appends to segment w of its outputs by counting in a register (one wave64 ballot per append,
+//   no atomics on queue tails); a wave stores its counts once, at its end, and the next launch's
+//   wave w reads them on the device.
+//   accumulate   wave reduction per pixel run, then one atomic instruction for (r, g, b), into the
+//                render's own sums (doubles); k_fold adds them to the caller's float buffer at the end
 //   k_resolve    accum / spp -> tone map -> float colour buffer + flipped 8-bit rows
-// Ray counts stay in device memory: every launch is a persistent grid that strides over the
-// count it reads; the host looks at the counters once per chunk of primary samples.
+// The host launches every depth of a chunk back to back; it looks at the device once per chunk (one
+// word: did a launch leave rays behind?) only for scenes with two-child materials, else never.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time (rccl())
 #include <dlfcn.h>
@@ -1112,6 +1115,10 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		two_queues = true;
 		PtxStatus zs = size_queues(true);
 		if (zs != PTX_OK) return zs;
+		// With two-child materials and so little memory that a wave gets fewer than four 64-sample units of a chunk,
+		// a segment's share of such materials swings too far for the halved take to hold: a quarter of the chunks
+		// left rays behind (2 GiB on the mesh scene at 1920x1080: 1 057 ms per image against 845 the careful way).
+		if (can_remain && take0 < 256) return careful_chunks(0, total);
 		// what a chunk may have to put back: its pixels of the sums (a chunk is a run of consecutive pixels), the work counters
 		const uint64_t band_pixels = std::min<uint64_t>(chunk / ns + 2, (uint64_t) rp->width * rp->height);
 		if (can_remain) {

@@ -174,6 +174,7 @@ struct NoCount {
 	__device__ __forceinline__ void sphere() {}
 	__device__ __forceinline__ void box() {}
 	__device__ __forceinline__ void xform() {}
+	__device__ __forceinline__ void needed() {}
 	__device__ __forceinline__ unsigned get(int) const { return 0; }
 };
 struct TestCount {
@@ -182,7 +183,16 @@ struct TestCount {
 	__device__ __forceinline__ void tri() { ++n[1]; }
 	__device__ __forceinline__ void sphere() { ++n[2]; }
 	__device__ __forceinline__ void box() { ++n[3]; }
+#ifdef PTX_CENSUS_NEEDED
+	// a build for one question - how much of the frame-0 leaf work is owed to the other rays of the wave? - in which
+	// the last counter holds, per lane, the leaf tests the lane's OWN ray asked for (its own filter passed), to set
+	// against the sphere / box / triangle counters, which count every lane of a wave that ran a test
+	__device__ __forceinline__ void xform() {}
+	__device__ __forceinline__ void needed() { ++n[4]; }
+#else
 	__device__ __forceinline__ void xform() { ++n[4]; }
+	__device__ __forceinline__ void needed() {}
+#endif
 	__device__ __forceinline__ unsigned get(int k) const { return n[k]; }
 };
 
@@ -562,7 +572,9 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	}
 	for (int i = 0; i < S.n_root_prims; ++i) {
 		tc.slab();
-		if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, cull_limit(best.t)))) continue;
+		const bool may = may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, cull_limit(best.t));
+		if (may) tc.needed();
+		if (!__ballot(may)) continue;
 		const DevRootPrim P = kload(S.root_prims_k + i);
 		float t;
 		bool hit = root_prim_t(S, P, o, d, pre, t, tc);
@@ -665,7 +677,9 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 		const float limit = cull_limit(range);
 		for (int i = 0; i < S.n_root_prims; ++i) {
 			tc.slab();
-			if (!__ballot(may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, limit))) continue;
+			const bool may = may_hit_box(kload(S.root_bound_k + 2 * i), kload(S.root_bound_k + 2 * i + 1), pre, limit);
+			if (may) tc.needed();
+			if (!__ballot(may)) continue;
 			const DevRootPrim P = kload(S.root_prims_k + i);
 			if (root_prim_t(S, P, o, d, pre, t, tc) && t <= range) {
 				if (RB && S.n_guards) {

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Per-depth test counts per ray of a library build: scripts/census_depth.py <lib> [scene] [aa]"""
+"""Per-depth test counts per ray of a library build: scripts/census_depth.py <lib | -> [scene] [aa]
+With a library built with -DPTX_CENSUS_NEEDED (hipcc ... -DPTX_CENSUS_NEEDED -shared -o build/libptx_needed.so ptx.hip
+ptx_bvh.cpp -ldl) the last column is the frame-0 leaf tests a lane's own ray asked for; sphere + box + tri are what
+the waves executed per ray."""
 import importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
