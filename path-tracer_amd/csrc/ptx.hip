@@ -903,11 +903,13 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	auto count_of = [&](unsigned depth) { return M.counts + (size_t) depth * M.max_seg; };
 	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * M.max_seg; };
 	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * M.max_seg; };
+	unsigned* const order = M.counts + (size_t) 3 * (kMaxBounces + 2) * M.max_seg;
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
 	// the general variant of the traversal kernels: frame-0 leaves under a BVH of their own, or a split root
 	// (the fused kernel has no such variant: it takes the leaves one by one and knows no octants)
 	const bool rb = sc->dev.root_bvh != 0 || sc->dev.n_guards != 0;
+	static const bool use_order = !getenv("PTX_NO_ORDER");
 
 	// Sizing (see the note on queues in ptx_kernels.hpp): what a launch takes of segment w of
 	// its input lands in segment w of its outputs, at most `per_ray` records per input ray in
@@ -950,7 +952,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	}
 	unsigned nqueues = 0, n_seg = 0, seg_cap = 0, take = 0, take0 = 0;
 	uint64_t capd = 0, chunk = 0;
-	dim3 grid(1);
+	dim3 grid(1), walk_grid(1);  // a grid is n_seg waves: in workgroups of kBlock (shading) or kWalkBlock (the kernels that walk)
 	auto queue_at = [&](unsigned index) {  // queue `index` of the block: capd slots of 48 bytes, as three planes
 		RayQueue q;
 		q.a = M.qmem + (uint64_t) index * capd * 3;
@@ -981,6 +983,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		take0 = two_queues && can_remain ? std::max(64u, (take / 2) & ~63u) : take;
 		chunk = (uint64_t) take0 * n_seg;  // primary samples per launch (at most 2^30)
 		grid = dim3(n_seg / (kBlock / 64));
+		walk_grid = dim3(n_seg / (kWalkBlock / 64));
 		A.seg_cap = seg_cap;
 		A.n_seg = n_seg;
 		if (staged) {  // shadow queue and hit records behind the ray queues
@@ -989,17 +992,54 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		}
 		return PTX_OK;
 	};
+#ifdef PTX_TIMELINE
+	// PTX_TIMELINE="kind:depth:chunk:file": the wave table of that launch (kind 0 closest hit, 1 shading, 2 shadow), written once
+	static int tl_kind = -2, tl_depth = -1, tl_chunk = 0;
+	static std::string tl_path;
+	static bool tl_done = false;
+	if (tl_kind == -2 && getenv("PTX_TIMELINE")) {
+		char buf[512] = {0};
+		if (sscanf(getenv("PTX_TIMELINE"), "%d:%d:%d:%500s", &tl_kind, &tl_depth, &tl_chunk, buf) == 4) tl_path = buf;
+	}
+	int tl_chunks_seen = -1;
+	auto timeline_dump = [&](int kind, unsigned d) {
+		if (d == 0 && kind == 0) ++tl_chunks_seen;
+		// (kind or depth -1: every kind / every depth of the chunk, one file each)
+		if (tl_done || (tl_kind >= 0 && kind != tl_kind) || (tl_depth >= 0 && (int) d != tl_depth) || tl_chunks_seen != tl_chunk) return;
+		if (tl_kind >= 0 && tl_depth >= 0) tl_done = true;
+		(void) hipStreamSynchronize(stream);
+		std::vector<unsigned long long> t(4 * (size_t) kMaxSeg);
+		(void) hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_timeline), t.size() * sizeof(unsigned long long));
+		const std::string path = tl_path + (tl_kind < 0 || tl_depth < 0 ? ".k" + std::to_string(kind) + ".d" + std::to_string(d) : std::string());
+		if (FILE* f = fopen(path.c_str(), "wb")) {
+			unsigned hdr[4] = {n_seg, seg_cap, (unsigned) kind, d};
+			fwrite(hdr, sizeof hdr, 1, f);
+			fwrite(t.data(), sizeof(unsigned long long), 4 * (size_t) n_seg, f);
+			fclose(f);
+		}
+	};
+#define PTX_TL(kind, d) timeline_dump(kind, d)
+#else
+#define PTX_TL(kind, d) (void) 0
+#endif
 	auto launch_depth = [&](unsigned d) -> PtxStatus {
 		if (!staged) {
 			HIP_TRY(tick(0, d, true));
 			auto kern = d == 0 ? (ip ? k_bounce<true, true> : k_bounce<true, false>) : (ip ? k_bounce<false, true> : k_bounce<false, false>);
-			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), 0, stream, A);
 			HIP_TRY(tick(0, d, false));
 			launches += 1;
 			return PTX_OK;
 		}
 		A.shadow_count = shadow_count_of(d);
 		A.hit_count = hit_count_of(d);
+		// the segments of a depth > 0, fullest first, for the three kernels of the depth (hits and shadow rays follow the rays)
+		A.order = nullptr;
+		if (d > 0 && use_order && n_seg >= 1024) {
+			hipLaunchKernelGGL(k_order, dim3(1), dim3(kOrderBlock), 0, stream, A.in_count, n_seg, seg_cap, A.in_first, A.in_take, order);
+			A.order = order;
+			launches += 1;
+		}
 		HIP_TRY(tick(0, d, true));
 		{
 			auto pick = [&](auto counted) {
@@ -1007,7 +1047,8 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 				return d == 0 ? (rb ? k_trace<true, true, TC> : k_trace<true, false, TC>) : (rb ? k_trace<false, true, TC> : k_trace<false, false, TC>);
 			};
 			auto kern = count_tests ? pick(TestCount{}) : pick(NoCount{});
-			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), 0, stream, A);
+			PTX_TL(0, d);
 		}
 		HIP_TRY(tick(0, d, false));
 		HIP_TRY(tick(1, d, true));
@@ -1023,12 +1064,14 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 			A.stage_lights = (unsigned) std::min(std::max(sc->dev.n_lights, 0), kStageLights);
 			const size_t stage_bytes = (size_t) (kBlock / 64) * shade_stage_f4(A.stage_children, A.stage_lights) * sizeof(float4);
 			hipLaunchKernelGGL(kern, grid, dim3(kBlock), stage_bytes, stream, A);
+			PTX_TL(1, d);
 		}
 		HIP_TRY(tick(1, d, false));
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
 			auto kern = count_tests ? (rb ? k_shadow<true, TestCount> : k_shadow<false, TestCount>) : (rb ? k_shadow<true, NoCount> : k_shadow<false, NoCount>);
-			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), 0, stream, A);
+			PTX_TL(2, d);
 			HIP_TRY(tick(2, d, false));
 			launches += 1;
 		}
@@ -1367,9 +1410,9 @@ static PtxStatus run_intersect(PtxScene* sc, IntersectArgs& A, int64_t n, int32_
 	A.pos = static_cast<float*>(d_pos);
 	A.nrm = static_cast<float*>(d_nrm);
 	A.rdir = static_cast<float*>(d_rd);
-	unsigned grid = (unsigned) std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t) sc->grid);
+	unsigned grid = (unsigned) std::min<int64_t>((n + kWalkBlock - 1) / kWalkBlock, (int64_t) sc->grid * (kBlock / kWalkBlock));
 	if (grid == 0) grid = 1;
-	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kBlock), 0, nullptr, A);
+	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kWalkBlock), 0, nullptr, A);
 	TRY_C(hipGetLastError());
 	TRY_C(hipDeviceSynchronize());
 	if (prim) TRY_C(hipMemcpy(prim, d_prim, (size_t) n * 4, hipMemcpyDeviceToHost));

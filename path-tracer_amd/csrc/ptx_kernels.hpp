@@ -14,6 +14,14 @@ using namespace ptxd;
 namespace {
 
 constexpr int kBlock = 256;  // 4 wave64 per workgroup
+// Workgroup of the kernels that walk (closest hit, shadow rays, the fused kernel, the parity tap).  Their waves share
+// nothing - every wave has its own queue segment, stack and ring - so one wave is a workgroup of its own: a
+// workgroup's registers and LDS are released only when its LAST wave ends, and waves whose segments cost unequal
+// time would otherwise hold three finished waves' slots empty until the slowest is through.
+#ifndef PTX_WALK_BLOCK
+#define PTX_WALK_BLOCK 64
+#endif
+constexpr int kWalkBlock = PTX_WALK_BLOCK;
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 2  // waves per SIMD the bounce kernel's register budget is sized for
 #endif
@@ -22,8 +30,11 @@ static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH lea
 constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
 constexpr unsigned kMaxBounces = 63;
 // A queue is cut into segments, one per wave of a launch (see the note on queues at the kernels).
-constexpr unsigned kMaxSeg = 16384;  // most segments = waves of a grid: four rounds of the workgroups an MI355X keeps resident
-constexpr size_t count_bytes(unsigned max_seg) { return (size_t) 3 * (kMaxBounces + 2) * max_seg * sizeof(unsigned); }  // per depth: ray, shadow-ray and hit counts of every segment
+#ifndef PTX_MAX_SEG
+#define PTX_MAX_SEG 16384
+#endif
+constexpr unsigned kMaxSeg = PTX_MAX_SEG;  // most segments = waves of a grid: four rounds of the workgroups an MI355X keeps resident
+constexpr size_t count_bytes(unsigned max_seg) { return ((size_t) 3 * (kMaxBounces + 2) + 1) * max_seg * sizeof(unsigned); }  // per depth: ray, shadow-ray and hit counts of every segment; one more row: the order the segments of a depth are taken in
 
 // ---------------------------------------------------------------------------
 // device scene
@@ -275,7 +286,7 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 					c0 = c1;
 					c1 = tmp;
 				}
-				stk[sp * kBlock] = c1;
+				stk[sp * kWalkBlock] = c1;
 				++sp;
 				cur = c0;
 			} else if (h0) {
@@ -284,7 +295,7 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 				cur = c1;
 			} else if (sp > 0) {
 				--sp;
-				cur = stk[sp * kBlock];
+				cur = stk[sp * kWalkBlock];
 			} else {
 				cur = kDone;
 			}
@@ -319,7 +330,7 @@ __device__ __forceinline__ bool bvh_walk(const float4* __restrict__ nodes, const
 		}
 		if (sp > 0) {
 			--sp;
-			cur = stk[sp * kBlock];
+			cur = stk[sp * kWalkBlock];
 		} else {
 			cur = kDone;
 		}
@@ -496,7 +507,7 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 					c0 = c1;
 					c1 = tmp;
 				}
-				stk[sp * kBlock] = c1;
+				stk[sp * kWalkBlock] = c1;
 				++sp;
 				cur = c0;
 			} else if (h0) {
@@ -505,7 +516,7 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 				cur = c1;
 			} else if (sp > 0) {
 				--sp;
-				cur = stk[sp * kBlock];
+				cur = stk[sp * kWalkBlock];
 			} else {
 				cur = kDone;
 			}
@@ -539,7 +550,7 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 		}
 		if (sp > 0) {
 			--sp;
-			cur = stk[sp * kBlock];
+			cur = stk[sp * kWalkBlock];
 		} else {
 			cur = kDone;
 		}
@@ -1149,6 +1160,7 @@ struct BounceArgs {
 	float4* hits;              // hit records: (t, bits(prim id), bits(where), bits(ray))
 	                           // ray = the sample's index in the batch (depth 0) or the ray's slot in `in`
 	unsigned* hit_count;
+	const unsigned* order;     // wave i of the grid takes segment order[i] (fullest first, see k_order); NULL: segment i
 };
 
 // Where the sums of a render go.  A pixel of a 10 000-sample image receives some 10^5 additions; into a float that
@@ -1185,8 +1197,41 @@ typedef const __attribute__((address_space(4))) struct BounceArgs KArgs;
 #define PTX_ARGS_IN_PLACE(ka) KArgs* ka = (KArgs*) __builtin_amdgcn_kernarg_segment_ptr()
 #define PTX_ARGS_AGAIN(ka) asm volatile("" : "+s"(ka))
 // this wave's number: the same in every lane, and known to the compiler to be (scalar registers, scalar loads)
-__device__ __forceinline__ unsigned wave_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)); }
+template <int BLOCK = kBlock>
+__device__ __forceinline__ unsigned wave_id() { return __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)); }
 
+// The segment wave `w` of a grid works on.  The segments of a depth > 0 are unequally full - a wave's few pixels lie
+// on glass or they do not - and a grid ends when its last wave ends: taken in the order of their numbers, a full
+// segment that starts late keeps the chip waiting, nearly empty, for one wave.  k_order lists them fullest first.
+__device__ __forceinline__ unsigned segment_of(const unsigned* order, unsigned w) {
+	return order ? __builtin_amdgcn_readfirstlane(order[w]) : w;
+}
+#ifdef PTX_TIMELINE
+// A build for one question - when do the waves of a launch start and end, and where? - in which every wave of the queue
+// kernels leaves (start, end, records, hardware id) in a table the host dumps (scripts/timeline.py).
+__device__ unsigned long long g_timeline[4 * kMaxSeg];
+struct WaveTimer {
+	unsigned long long t0;
+	unsigned slot, seg;
+	__device__ __forceinline__ WaveTimer(unsigned wave_slot, unsigned segment) : t0(wall_clock64()), slot(wave_slot), seg(segment) {}
+	__device__ __forceinline__ void done(unsigned records) const {
+		if (lane_id() == 0 && slot < kMaxSeg) {
+			unsigned hw, xcc;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+			g_timeline[4 * slot] = t0;
+			g_timeline[4 * slot + 1] = wall_clock64();
+			g_timeline[4 * slot + 2] = records | ((unsigned long long) seg << 32);
+			g_timeline[4 * slot + 3] = (unsigned long long) hw | ((unsigned long long) xcc << 32);
+		}
+	}
+};
+#else
+struct WaveTimer {
+	__device__ __forceinline__ WaveTimer(unsigned, unsigned) {}
+	__device__ __forceinline__ void done(unsigned) const {}
+};
+#endif
 // records of segment `wave` of a queue that a launch takes, given the segment's count
 __device__ __forceinline__ unsigned taken(unsigned count, unsigned seg_cap, unsigned first, unsigned take) {
 	unsigned c = min(count, seg_cap);
@@ -1291,11 +1336,11 @@ __device__ __forceinline__ void stat_add_tests<NoCount>(unsigned long long*, int
 
 // ---- fused pipeline: one kernel per depth -----------------------------------------------
 template <bool PRIMARY, bool INTPOW>
-__global__ __launch_bounds__(kBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
-	__shared__ int lds_stack[kStack * kBlock];
+__global__ __launch_bounds__(kWalkBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
+	__shared__ int lds_stack[kStack * kWalkBlock];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned wave = wave_id();
+	const unsigned wave = wave_id<kWalkBlock>();
 	unsigned n;
 	const unsigned steps = wave_steps<PRIMARY>(A, wave, n);
 	const size_t seg_base = (size_t) wave * A.seg_cap;
@@ -1361,15 +1406,16 @@ constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from whi
 #define PTX_PRIMARY_WAVES 5
 #endif
 template <bool PRIMARY, bool RB, class TC>
-__global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A_) {
+__global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
-	__shared__ int lds_stack[kStack * kBlock];
-	__shared__ float4 ring_mem[(kBlock / 64) * kRing];
+	__shared__ int lds_stack[kStack * kWalkBlock];
+	__shared__ float4 ring_mem[(kWalkBlock / 64) * kRing];
 	int* stk = lds_stack + threadIdx.x;
 	volatile float4* ring = ring_mem + (threadIdx.x >> 6) * kRing;
 	const unsigned lane = lane_id();
-	const unsigned wave = wave_id();
+	const unsigned wave = PRIMARY ? wave_id<kWalkBlock>() : segment_of(A.order, wave_id<kWalkBlock>());
+	const WaveTimer timer(wave_id<kWalkBlock>(), wave);
 	unsigned n;
 	const unsigned steps = wave_steps<PRIMARY>(A, wave, n);
 	if (!PRIMARY && A.flag_remainder && A.in_take && lane == 0 && min(A.in_count[wave], A.seg_cap) > A.in_first + A.in_take) atomicAdd(&A.counters->remainder, 1ull);
@@ -1504,6 +1550,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) v
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 0, cnt_trace);
 	stat_add_tests(st, 3, tc);
+	timer.done(PRIMARY ? steps * 64 : n);
 #undef A
 }
 
@@ -1600,7 +1647,8 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (I
 		stage.shadow_b = stage.shadow_a + 64 * A.stage_lights;
 	}
 	const unsigned lane = lane_id();
-	const unsigned wave = wave_id();
+	const unsigned wave = segment_of(A.order, wave_id());
+	const WaveTimer timer(wave_id(), wave);
 	const unsigned n = min(A.hit_count[wave], A.seg_cap);
 	const unsigned steps = (n + 63) >> 6;
 	const size_t seg_base = (size_t) wave * A.seg_cap;
@@ -1659,6 +1707,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (I
 			A.out_count[wave] = 0;
 			A.shadow_count[wave] = 0;
 		}
+		timer.done(0);
 		return;
 	}
 	float4 hit_next = fetch_hit(0);  // hit records of the step after the current one
@@ -1800,6 +1849,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (I
 	unsigned long long* st = stat_slot(A, wave);
 	stat_add(st, 1, cnt_shadow);
 	stat_add(st, 2, cnt_hits);
+	timer.done(n);
 #undef A
 }
 
@@ -1809,13 +1859,14 @@ template <bool RB, class TC>
 #ifndef PTX_SHADOW_WAVES
 #define PTX_SHADOW_WAVES 5
 #endif
-__global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
+__global__ __launch_bounds__(kWalkBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
-	__shared__ int lds_stack[kStack * kBlock];
+	__shared__ int lds_stack[kStack * kWalkBlock];
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
-	const unsigned wave = wave_id();
+	const unsigned wave = segment_of(A.order, wave_id<kWalkBlock>());
+	const WaveTimer timer(wave_id<kWalkBlock>(), wave);
 	const unsigned n = min(A.shadow_count[wave], A.seg_cap);
 	const unsigned steps = (n + 63) >> 6;
 	const size_t seg_base = (size_t) wave * A.seg_cap;
@@ -1867,7 +1918,44 @@ __global__ __launch_bounds__(kBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs 
 	}
 	accumulate(A, prev_pix, prev_c, prev_lit);
 	stat_add_tests(stat_slot(A, wave), 3 + kTestKinds, tc);
+	timer.done(n);
 #undef A
+}
+
+// order[] = the segments of one depth sorted by the number of 64-record steps a launch takes of them, most first (a
+// counting sort in one workgroup: n_seg is some thousand).  Segments with equal step counts come in any order: the
+// order decides when a segment is worked on, never what is computed.
+constexpr int kOrderBlock = 1024;
+constexpr int kOrderBins = 256;
+__global__ __launch_bounds__(kOrderBlock) void k_order(const unsigned* __restrict__ count, unsigned n_seg, unsigned seg_cap, unsigned first, unsigned take,
+                                                       unsigned* __restrict__ order) {
+	__shared__ unsigned bin[kOrderBins];
+	__shared__ unsigned start[kOrderBins];
+	const unsigned max_steps = (seg_cap + 63) / 64;
+	auto key_of = [&](unsigned seg) {
+		const unsigned steps = (taken(count[seg], seg_cap, first, take) + 63) >> 6;
+		const unsigned k = max_steps < (unsigned) kOrderBins ? steps : (unsigned) ((unsigned long long) steps * (kOrderBins - 1) / max_steps);
+		return (unsigned) (kOrderBins - 1) - min(k, (unsigned) (kOrderBins - 1));  // most steps first
+	};
+	for (unsigned i = threadIdx.x; i < (unsigned) kOrderBins; i += kOrderBlock) bin[i] = 0;
+	__syncthreads();
+	for (unsigned s = threadIdx.x; s < n_seg; s += kOrderBlock) atomicAdd(&bin[key_of(s)], 1u);
+	__syncthreads();
+	if (threadIdx.x < 64) {  // exclusive prefix sums of the bins: four bins per lane, then across the lanes
+		const unsigned b0 = bin[4 * threadIdx.x], b1 = bin[4 * threadIdx.x + 1], b2 = bin[4 * threadIdx.x + 2], b3 = bin[4 * threadIdx.x + 3];
+		unsigned sum = b0 + b1 + b2 + b3, incl = sum;
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned o = __shfl_up(incl, off);
+			if ((int) threadIdx.x >= off) incl += o;
+		}
+		const unsigned excl = incl - sum;
+		start[4 * threadIdx.x] = excl;
+		start[4 * threadIdx.x + 1] = excl + b0;
+		start[4 * threadIdx.x + 2] = excl + b0 + b1;
+		start[4 * threadIdx.x + 3] = excl + b0 + b1 + b2;
+	}
+	__syncthreads();
+	for (unsigned s = threadIdx.x; s < n_seg; s += kOrderBlock) order[atomicAdd(&start[key_of(s)], 1u)] = s;
 }
 
 // sums the statistic slots of one depth into the compact block the host reads
@@ -1918,10 +2006,10 @@ struct IntersectArgs {
 	float* rdir;
 };
 template <bool RB>
-__global__ __launch_bounds__(kBlock) void k_intersect(IntersectArgs A) {
-	__shared__ int lds_stack[kStack * kBlock];
+__global__ __launch_bounds__(kWalkBlock) void k_intersect(IntersectArgs A) {
+	__shared__ int lds_stack[kStack * kWalkBlock];
 	int* stk = lds_stack + threadIdx.x;
-	for (long long i = (long long) blockIdx.x * kBlock + threadIdx.x; i < A.n; i += (long long) gridDim.x * kBlock) {
+	for (long long i = (long long) blockIdx.x * kWalkBlock + threadIdx.x; i < A.n; i += (long long) gridDim.x * kWalkBlock) {
 		f3 o, d;
 		if (A.d) {
 			o = ld3(A.o + 3 * i);
