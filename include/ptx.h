@@ -36,7 +36,7 @@ extern "C" {
 typedef enum PtxStatus {
 	PTX_OK = 0,
 	PTX_ERR_INVALID = 1,     /* bad argument / malformed scene description            */
-	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (nested transformed Composites, non-triangle leaves inside a mesh) */
+	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (spheres, boxes or moved triangles inside a transformed Composite; transformed Composites more than 8 deep, or inside one another under a split root) */
 	PTX_ERR_DEVICE = 3,      /* HIP call failed, or no gfx950 device                  */
 	PTX_ERR_OVERFLOW = 4,    /* a ray queue filled up: result discarded, see message  */
 	PTX_ERR_NOMEM = 5
@@ -63,17 +63,25 @@ typedef struct PtxCamera {
 /*
  * A frame is a Composite that changes coordinates and filters rays with its bounds_ box
  * (framework/composite.cpp:75-103): frame 0 is scene.root, every other frame is a
- * transformed child Composite of the root (a loaded OBJ mesh).  Octants and OBJ
- * sub-objects (identity transform) are NOT frames; they only show up as `levels`.
- *   bounds_min/max  the frame's bounds_ box, in its PARENT's space
- *   levels_up       Composites between this frame and the root, the root included,
- *                   the frame excluded (each one re-normalises the normal, :100)
+ * transformed Composite (a loaded OBJ mesh; a sub-object of one that a caller moved with
+ * find_child(..)->translate / rotate / scale, composite.cpp:112-114, :168-181).  Octants and OBJ
+ * sub-objects with the identity transform are NOT frames; they only show up as `levels`.
+ * A frame may lie inside another frame (a transformed Composite below a transformed Composite),
+ * at most 8 deep; Composite::intersect then tests one bounds_ box and changes coordinates once
+ * per level, and so does the library.  Frames are listed depth first: a frame's parent comes
+ * before it.
+ *   bounds_min/max  the frame's bounds_ box, in the space of the frame it lies in (as the
+ *                   reference leaves it: a parent's box is not rebuilt when a child moves)
+ *   parent          the frame this one lies in (0 = directly under the root or its octants)
+ *   levels_up       parent 0: Composites between this frame and the root, the root included,
+ *                   the frame excluded; parent > 0: Composites strictly between this frame and
+ *                   its parent frame's Composite (each one re-normalises the normal, :100)
  */
 typedef struct PtxFrame {
 	float world[16];
 	float world_inv[16];
 	float bounds_min[3], bounds_max[3];
-	int32_t parent;    /* -1 for frame 0, 0 otherwise */
+	int32_t parent;    /* -1 for frame 0 */
 	int32_t levels_up; /* 0 for frame 0 */
 } PtxFrame;
 
@@ -188,8 +196,8 @@ void ptx_jitter(uint32_t jitter_seed, uint32_t pixel, uint32_t sample, float* dx
  *           SIMD) at the price of hit records and shadow rays going through HBM.
  *   DEFAULT staged; fused for calls of fewer than 2^17 samples (previews, tiles), where the
  *           number of launches decides.
- * A scene with a split root (PtxSceneDesc::n_guards > 0) always takes the staged kernels, whatever
- * is asked for: the fused kernel does not know octants.
+ * A scene with a split root (PtxSceneDesc::n_guards > 0) or with frames inside frames always takes
+ * the staged kernels, whatever is asked for: the fused kernel knows neither.
  */
 typedef enum PtxPipeline { PTX_PIPELINE_DEFAULT = 0, PTX_PIPELINE_FUSED = 1, PTX_PIPELINE_STAGED = 2 } PtxPipeline;
 

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 from oracle_lib import Reference, SDF_DIR  # noqa: E402
 
-SCENES = ["cornell.sdf", "example.sdf", "example_fixed.sdf", "cornell_buster.sdf", "buster_closeup.sdf", "superhot_colored.sdf", "split_root.sdf", "odd_syntax.sdf", "odd_mesh.sdf"]
+SCENES = ["cornell.sdf", "example.sdf", "example_fixed.sdf", "cornell_buster.sdf", "buster_closeup.sdf", "superhot_colored.sdf", "split_root.sdf", "odd_syntax.sdf", "odd_mesh.sdf", "nested.sdf"]
 PARTS = ["frames", "prims", "materials", "lights", "ambient", "camera", "guards", "occurrences"]
 
 

@@ -899,6 +899,32 @@ void* oracle_load_scene(const char* sdf_path, const char* obj_dir) {
 	return sc.release();
 }
 void oracle_free_scene(void* s) { delete static_cast<Scene*>(s); }
+// root->find_child(a)->find_child(b)...->translate / rotate / scale, as a C++ caller of the reference moves a part of a
+// loaded mesh (composite.cpp:112-114, :168-181): path levels separated by '/', op 1 translate, 2 rotate (radians), 3 scale
+int oracle_transform_child(void* s, const char* path, int op, float a, float b, float c) {
+	Scene* sc = static_cast<Scene*>(s);
+	std::shared_ptr<Shape> shape = sc->root;
+	std::string rest(path ? path : "");
+	while (!rest.empty()) {
+		const size_t cut = rest.find('/');
+		const std::string name = rest.substr(0, cut);
+		rest = cut == std::string::npos ? std::string() : rest.substr(cut + 1);
+		auto* comp = dynamic_cast<Composite*>(shape.get());
+		if (!comp) return 1;
+		auto it = comp->children.find(name);
+		if (it == comp->children.end()) return 1;
+		shape = it->second;
+	}
+	if (op == 1) shape->do_translate(a, b, c);
+	else if (op == 2) shape->do_rotate(a, b, c);
+	else if (op == 3) shape->do_scale(a, b, c);
+	else return 1;
+	sc->rank.clear();
+	sc->leaves.clear();
+	sc->leaf_path.clear();
+	rank_leaves(*sc, *sc->root, "");
+	return 0;
+}
 const char* oracle_scene_error(void* s) { return static_cast<Scene*>(s)->error.c_str(); }
 int oracle_leaf_count(void* s) { return (int) static_cast<Scene*>(s)->leaves.size(); }
 // leaf name (as HitPoint::hit_object would carry it) and slash-joined path of rank i

@@ -25,6 +25,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+OPS = {"translate": 1, "rotate": 2, "scale": 3}
+
+
 class Port:
     """oracle/cpu_ref.cpp"""
 
@@ -68,6 +71,12 @@ class Port:
 
     def free(self, s):
         self.L.oracle_free_scene(s)
+
+    def transform_child(self, s, path, op, a, b, c):
+        """root->find_child(..)->...->translate / rotate / scale; op 'translate' | 'rotate' (radians) | 'scale'"""
+        self.L.oracle_transform_child.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        if self.L.oracle_transform_child(s, path.encode(), OPS[op], a, b, c) != 0:
+            raise RuntimeError("no child " + path)
 
     def leaf_names(self, s):
         n = self.L.oracle_leaf_count(s)
@@ -187,6 +196,11 @@ class Reference:
 
     def free(self, s):
         self.L.ref_free_scene(s)
+
+    def transform_child(self, s, path, op, a, b, c):
+        self.L.ref_transform_child.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_float]
+        if self.L.ref_transform_child(s, path.encode(), OPS[op], a, b, c) != 0:
+            raise RuntimeError("no child " + path)
 
     def render(self, s, w, h, aa, bounces, ppm_path="/tmp/_ref_out.ppm", **_):
         cb = np.zeros((h, w, 3), f32)

@@ -115,18 +115,6 @@ struct Walker {
 		out.prims.push_back(p);
 		out.names.push_back(s.name_);
 	}
-	void walk_mesh(Composite const& c, int frame, int levels) {
-		for (auto const& kv : c.children_) {
-			Shape const& s = *kv.second;
-			if (Composite const* sub = as_composite(s)) {
-				if (!is_identity(s.world_transform_)) throw std::string("nested transformed Composite");
-				walk_mesh(*sub, frame, levels + 1);
-			} else {
-				if (!dynamic_cast<Triangle const*>(&s) || !is_identity(s.world_transform_)) throw std::string("non-triangle leaf inside a mesh");
-				emit_leaf(s, frame, levels);
-			}
-		}
-	}
 	void frame_of(Composite const& c, int parent, int levels_up, PtxFrame& f) {
 		std::memcpy(f.world, &c.world_transform_[0][0], sizeof f.world);
 		std::memcpy(f.world_inv, &c.world_transform_inv_[0][0], sizeof f.world_inv);
@@ -135,6 +123,26 @@ struct Walker {
 		f.bounds_max[0] = hi.x; f.bounds_max[1] = hi.y; f.bounds_max[2] = hi.z;
 		f.parent = parent;
 		f.levels_up = levels_up;
+	}
+	void walk_mesh(Composite const& c, int frame, int levels) {
+		for (auto const& kv : c.children_) {
+			Shape const& s = *kv.second;
+			if (Composite const* sub = as_composite(s)) {
+				if (!is_identity(s.world_transform_)) {  // a transformed Composite inside a transformed one: a frame inside this frame
+					if (!seen.emplace(&s, -(int) out.frames.size()).second) continue;
+					if (!sub->bounds_) throw std::string("Composite without bounds");
+					PtxFrame f{};
+					frame_of(*sub, frame, levels, f);
+					out.frames.push_back(f);
+					walk_mesh(*sub, (int) out.frames.size() - 1, 0);
+					continue;
+				}
+				walk_mesh(*sub, frame, levels + 1);
+			} else {
+				if (!dynamic_cast<Triangle const*>(&s) || !is_identity(s.world_transform_)) throw std::string("non-triangle leaf inside a mesh");
+				emit_leaf(s, frame, levels);
+			}
+		}
 	}
 	// c: the root (guard -1) or one of its octants (guard = its index in out.guards)
 	void walk_root(Composite const& c, int levels, int guard) {
@@ -210,6 +218,27 @@ void* ref_flatten(void* scene_ptr) {
 		out->error = e;
 	}
 	return out;
+}
+// scene.root->find_child(a)->find_child(b)...->translate / rotate / scale with the reference's own methods
+// (composite.cpp:112-114, :168-181): path levels separated by '/', op 1 translate, 2 rotate (radians), 3 scale.
+// (find_child itself dereferences end() for a name that is not there, so the name is looked up first)
+int ref_transform_child(void* scene_ptr, const char* path, int op, float a, float b, float c) {
+	Scene* scene = static_cast<Scene*>(scene_ptr);
+	std::shared_ptr<Shape> shape = scene->root;
+	std::string rest(path ? path : "");
+	while (!rest.empty()) {
+		const size_t cut = rest.find('/');
+		const std::string name = rest.substr(0, cut);
+		rest = cut == std::string::npos ? std::string() : rest.substr(cut + 1);
+		auto comp = std::dynamic_pointer_cast<Composite>(shape);
+		if (!comp || comp->children_.find(name) == comp->children_.end()) return 1;
+		shape = comp->find_child(name);
+	}
+	if (op == 1) shape->translate(a, b, c);
+	else if (op == 2) shape->rotate(a, b, c);
+	else if (op == 3) shape->scale(a, b, c);
+	else return 1;
+	return 0;
 }
 void ref_flat_free(void* h) { delete static_cast<Flat*>(h); }
 const char* ref_flat_error(void* h) { return static_cast<Flat*>(h)->error.c_str(); }

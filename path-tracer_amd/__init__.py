@@ -175,6 +175,7 @@ def host_lib():
     H.pth_free_scene.restype = None
     H.pth_scene_desc.restype = C.POINTER(PtxSceneDesc)
     H.pth_scene_desc.argtypes = [C.c_void_p]
+    H.pth_scene_transform_child.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_float]
     H.pth_prim_name.restype = C.c_char_p
     H.pth_prim_name.argtypes = [C.c_void_p, C.c_int]
     H.pth_prim_path.restype = C.c_char_p
@@ -290,6 +291,14 @@ class HostScene:
             self.close()
         except Exception:
             pass
+
+    def transform_child(self, path, op, a, b, c):
+        """What a C++ caller does after load_scene to move a part of a loaded mesh:
+        root->find_child(..)->...->translate / rotate (radians) / scale; `path` = names joined by '/'.
+        The scene is flattened again (device scenes made from it before keep the old state)."""
+        if self._H.pth_scene_transform_child(self.handle, path.encode(), {"translate": 1, "rotate": 2, "scale": 3}[op], a, b, c) != 0:
+            raise RuntimeError(self._H.pth_last_error().decode())
+        self.desc = self._H.pth_scene_desc(self.handle)
 
     @property
     def n_prims(self):

@@ -41,6 +41,36 @@ void* pth_load_scene(const char* sdf_path, const char* obj_dir) {
 }
 void pth_free_scene(void* h) { delete static_cast<HostScene*>(h); }
 
+// What a C++ caller of the reference does after load_scene to move a part of a loaded mesh:
+// scene.root->find_child(a)->find_child(b)...->translate / rotate / scale (framework/composite.cpp:112-114,
+// :168-181; shape.cpp:17-36).  `path` names the child, levels separated by '/'; op 1 = translate(a, b, c),
+// 2 = rotate(yaw a, pitch b, roll c; radians), 3 = scale(a, b, c).  The scene is flattened again.
+int pth_scene_transform_child(void* h, const char* path, int op, float a, float b, float c) {
+	auto* hs = static_cast<HostScene*>(h);
+	try {
+		std::shared_ptr<Shape> shape = hs->scene.root;
+		std::string rest(path ? path : "");
+		while (!rest.empty()) {
+			const size_t cut = rest.find('/');
+			const std::string name = rest.substr(0, cut);
+			rest = cut == std::string::npos ? std::string() : rest.substr(cut + 1);
+			if (shape->kind() != Shape::Kind::composite) throw SceneError{"'" + shape->get_name() + "' has no children"};
+			shape = static_cast<Composite&>(*shape).find_child(name);
+		}
+		if (op == 1) shape->translate(a, b, c);
+		else if (op == 2) shape->rotate(a, b, c);
+		else if (op == 3) shape->scale(a, b, c);
+		else throw SceneError{"unknown transform"};
+		hs->flat = flatten_scene(hs->scene);
+		return 0;
+	} catch (SceneError const& e) {
+		g_err = e.message;
+	} catch (std::exception const& e) {
+		g_err = e.what();
+	}
+	return 1;
+}
+
 const PtxSceneDesc* pth_scene_desc(void* h) { return &static_cast<HostScene*>(h)->flat.desc; }
 const char* pth_prim_name(void* h, int i) { return static_cast<HostScene*>(h)->flat.prim_names[(size_t) i].c_str(); }
 const char* pth_prim_path(void* h, int i) { return static_cast<HostScene*>(h)->flat.prim_paths[(size_t) i].c_str(); }

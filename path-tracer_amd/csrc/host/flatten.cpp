@@ -90,6 +90,21 @@ struct Walker {
 		out.prim_materials.push_back(s.material());
 	}
 
+	// the frame a transformed Composite becomes: `parent` the frame it lies in, `levels` the Composites between the two
+	// (for a child of the root: up to the root, the root included)
+	static PtxFrame frame_of(Composite const& sub, int parent, int levels) {
+		if (!sub.bounds()) throw SceneError{"Composite '" + sub.get_name() + "' has no bounds: call build_octree()"};
+		PtxFrame f{};
+		std::memcpy(f.world, sub.world_transform().data(), sizeof f.world);
+		std::memcpy(f.world_inv, sub.world_transform_inv().data(), sizeof f.world_inv);
+		vec3 lo = sub.bounds()->min_corner(), hi = sub.bounds()->max_corner();
+		f.bounds_min[0] = lo.x; f.bounds_min[1] = lo.y; f.bounds_min[2] = lo.z;
+		f.bounds_max[0] = hi.x; f.bounds_max[1] = hi.y; f.bounds_max[2] = hi.z;
+		f.parent = parent;
+		f.levels_up = levels;
+		return f;
+	}
+
 	// inside a mesh frame: `levels` Composites lie between the leaf and the frame's Composite
 	void walk_mesh(Composite const& c, int frame, int levels, std::string const& path, int depth) {
 		++out.composites;
@@ -97,9 +112,14 @@ struct Walker {
 		for (auto const& kv : c.children()) {
 			Shape const& s = *kv.second;
 			if (s.kind() == Shape::Kind::composite) {
-				if (!is_identity(s.world_transform()))
-					throw SceneError{"Composite '" + s.get_name() + "': a transformed Composite inside another transformed Composite is not supported"};
-				walk_mesh(static_cast<Composite const&>(s), frame, levels + 1, path + s.get_name() + "/", depth + 1);
+				auto const& sub = static_cast<Composite const&>(s);
+				if (!is_identity(sub.world_transform())) {  // a transformed Composite inside a transformed one: a frame inside this frame
+					if (!seen.emplace(&s, -(int) out.frames.size()).second) continue;  // (listed at its first encounter, like a leaf)
+					out.frames.push_back(frame_of(sub, frame, levels));
+					walk_mesh(sub, (int) out.frames.size() - 1, 0, path + sub.get_name() + "/", depth + 1);
+					continue;
+				}
+				walk_mesh(sub, frame, levels + 1, path + s.get_name() + "/", depth + 1);
 			} else {
 				++out.leaf_entries;
 				if (s.kind() != Shape::Kind::triangle || !is_identity(s.world_transform()))
@@ -143,17 +163,8 @@ struct Walker {
 				out.occurrences.push_back(PtxOccurrence{guard, -1, -ins.first->second, 0});
 				continue;
 			}
-			if (!sub.bounds()) throw SceneError{"Composite '" + sub.get_name() + "' has no bounds: call build_octree()"};
-			PtxFrame f{};
-			std::memcpy(f.world, sub.world_transform().data(), sizeof f.world);
-			std::memcpy(f.world_inv, sub.world_transform_inv().data(), sizeof f.world_inv);
-			vec3 lo = sub.bounds()->min_corner(), hi = sub.bounds()->max_corner();
-			f.bounds_min[0] = lo.x; f.bounds_min[1] = lo.y; f.bounds_min[2] = lo.z;
-			f.bounds_max[0] = hi.x; f.bounds_max[1] = hi.y; f.bounds_max[2] = hi.z;
-			f.parent = 0;
-			f.levels_up = levels;
 			int idx = (int) out.frames.size();
-			out.frames.push_back(f);
+			out.frames.push_back(frame_of(sub, 0, levels));
 			out.occurrences.push_back(PtxOccurrence{guard, -1, idx, 0});
 			walk_mesh(sub, idx, 0, path + sub.get_name() + "/", depth + 1);
 		}

@@ -342,8 +342,17 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	if (D->n_materials > 0xffff) return fail(PTX_ERR_UNSUPPORTED, "more than 65535 materials");
 	if (!is_identity(D->frames[0].world) || D->frames[0].parent != -1)
 		return fail(PTX_ERR_UNSUPPORTED, "frame 0 must be the untransformed root Composite");
-	for (int f = 1; f < D->n_frames; ++f)
-		if (D->frames[f].parent != 0) return fail(PTX_ERR_UNSUPPORTED, "only children of the root may carry a transform (frame.parent must be 0)");
+	// frames inside frames: every frame names an earlier one as the frame it lies in, at most kMaxNest deep
+	bool nested = false;
+	for (int f = 1; f < D->n_frames; ++f) {
+		const int p = D->frames[f].parent;
+		if (p < 0 || p >= f) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": the frame it lies in must come earlier in the list (0 = the root)");
+		int depth = 1;
+		for (int a = p; a > 0; a = D->frames[a].parent) ++depth;
+		if (depth > kMaxNest) return fail(PTX_ERR_UNSUPPORTED, "frame " + std::to_string(f) + ": transformed Composites nested deeper than " + std::to_string(kMaxNest));
+		nested = nested || p > 0;
+	}
+	if (nested && D->n_guards > 0) return fail(PTX_ERR_UNSUPPORTED, "a split root (more than 64 children) together with transformed Composites inside transformed Composites");
 	// ---- octants of a split root
 	const bool guarded = D->n_guards > 0;
 	if (D->n_guards < 0 || D->n_occurrences < 0 || (guarded && (!D->guards || !D->occurrences)))
@@ -367,7 +376,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	}
 	// ---- every index and count the set-up below and the kernels rely on, before anything touches a device
 	for (int f = 1; f < D->n_frames; ++f)
-		if (D->frames[f].levels_up < 1 || D->frames[f].levels_up > 255)
+		if (D->frames[f].levels_up < (D->frames[f].parent == 0 ? 1 : 0) || D->frames[f].levels_up > 255)
 			return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": levels_up out of range");
 	for (int i = 0; i < D->n_prims; ++i) {
 		const PtxPrim& P = D->prims[i];
@@ -455,7 +464,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		const PtxFrame& F = D->frames[f];
 		bool ok = finite16(F.world) && finite16(F.world_inv);
 		for (int k = 0; k < 3; ++k) ok = ok && !std::isnan(F.bounds_min[k]) && !std::isnan(F.bounds_max[k]);
-		frame_ok[f] = ok;
+		frame_ok[f] = ok && frame_ok[F.parent];  // (a frame inside a dropped frame goes with it)
 	}
 	for (int i = 0; i < D->n_prims; ++i) {
 		const PtxPrim& P = D->prims[i];
@@ -472,12 +481,15 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			// by the Composites above it.
 			f3 n = mk(P.normal[0], P.normal[1], P.normal[2]);
 			if (P.frame > 0) {
-				const PtxFrame& F = D->frames[P.frame];
 				for (int k = 0; k < P.levels_in; ++k) n = up_one_level(n);
-				n = normalize(xform_dir(F.world, n));
-				// (split root: once for the root here, once more per octant level above the occurrence
-				// of the mesh a ray came through when the hit is shaded)
-				for (int k = 0; k < (guarded ? 1 : F.levels_up); ++k) n = up_one_level(n);
+				// (a frame inside a frame: the same again for every frame up the chain)
+				for (int a = P.frame; a > 0; a = D->frames[a].parent) {
+					const PtxFrame& F = D->frames[a];
+					n = normalize(xform_dir(F.world, n));
+					// (split root: once for the root here, once more per octant level above the occurrence
+					// of the mesh a ray came through when the hit is shaded)
+					for (int k = 0; k < (guarded ? 1 : F.levels_up); ++k) n = up_one_level(n);
+				}
 			} else if (P.kind == PTX_TRIANGLE) {
 				n = xform_dir(P.world, n);
 				for (int k = 0; k < (guarded ? 1 : P.levels_in); ++k) n = up_one_level(n);
@@ -549,6 +561,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		std::memcpy(G.bmin, F.bounds_min, sizeof G.bmin);
 		std::memcpy(G.bmax, F.bounds_max, sizeof G.bmax);
 		G.levels_up = F.levels_up;
+		G.parent = F.parent;
 		G.plain = pure_translation(F.world) && pure_translation(F.world_inv);
 		auto const& ids = frame_tris[f];
 		G.has_prims = !ids.empty();
@@ -690,6 +703,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(&S.frame_winv_k, &S.frame_winv, sizeof(void*));
 	std::memcpy(&S.lights_k, &S.lights, sizeof(void*));
 	S.n_root_prims = (int) root_prims.size();
+	S.nested = nested ? 1 : 0;
 	S.n_frames = D->n_frames;
 	S.n_lights = D->n_lights;
 	S.n_prims = D->n_prims;
@@ -874,7 +888,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	// instead of three is what counts when a launch holds little work (0.53 against 0.71 ms for 96x64, 4 spp)
 	const uint32_t pipeline = rp->pipeline & ~(uint32_t) (PTX_TRACE_ZERO_WEIGHT | PTX_REDUCE_RCCL);
 	A.all_children = (rp->pipeline & PTX_TRACE_ZERO_WEIGHT) ? 1u : 0u;
-	const bool staged = pipeline == PTX_PIPELINE_STAGED || (pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17)) || sc->dev.n_guards != 0;
+	const bool staged = pipeline == PTX_PIPELINE_STAGED || (pipeline == PTX_PIPELINE_DEFAULT && total >= (1ull << 17)) || sc->dev.n_guards != 0 || sc->dev.nested != 0;
 	sc->event_tag.clear();
 	sc->event_begin.clear();
 	// profiling: an event after every launch, which is the begin of the next launch as well when that
@@ -908,7 +922,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	const bool ip = sc->int_pow;
 	// the general variant of the traversal kernels: frame-0 leaves under a BVH of their own, or a split root
 	// (the fused kernel has no such variant: it takes the leaves one by one and knows no octants)
-	const bool rb = sc->dev.root_bvh != 0 || sc->dev.n_guards != 0;
+	const bool rb = sc->dev.root_bvh != 0 || sc->dev.n_guards != 0 || sc->dev.nested != 0;
 	static const bool use_order = !getenv("PTX_NO_ORDER");
 
 	// Sizing (see the note on queues in ptx_kernels.hpp): what a launch takes of segment w of
@@ -1054,7 +1068,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		HIP_TRY(tick(1, d, true));
 		{
 			// the small tables of the scene from LDS copies when they fit
-			const bool lt = A.S.n_root_prims <= kLdsRoot && A.S.n_frames <= kLdsFrames && A.S.n_materials <= kLdsMats;
+			const bool lt = A.S.n_root_prims <= kLdsRoot && A.S.n_frames <= kLdsFrames && A.S.n_materials <= kLdsMats && !A.S.nested;
 			auto pick = [&](auto primary) {
 				constexpr bool P = decltype(primary)::value;
 				return ip ? (lt ? k_shade<P, true, true> : k_shade<P, true, false>) : (lt ? k_shade<P, false, true> : k_shade<P, false, false>);
@@ -1412,7 +1426,7 @@ static PtxStatus run_intersect(PtxScene* sc, IntersectArgs& A, int64_t n, int32_
 	A.rdir = static_cast<float*>(d_rd);
 	unsigned grid = (unsigned) std::min<int64_t>((n + kWalkBlock - 1) / kWalkBlock, (int64_t) sc->grid * (kBlock / kWalkBlock));
 	if (grid == 0) grid = 1;
-	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kWalkBlock), 0, nullptr, A);
+	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards || sc->dev.nested ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kWalkBlock), 0, nullptr, A);
 	TRY_C(hipGetLastError());
 	TRY_C(hipDeviceSynchronize());
 	if (prim) TRY_C(hipMemcpy(prim, d_prim, (size_t) n * 4, hipMemcpyDeviceToHost));

@@ -77,7 +77,7 @@ struct DevFrame {  // a mesh Composite with its own transform and bounds: 64-B h
 	int32_t levels_up;
 	int32_t has_prims;
 	int32_t plain;      // transform is a pure translation
-	int32_t pad;
+	int32_t parent;     // the frame this one lies in (0: the root)
 };
 struct Mat16 {
 	float m[16];
@@ -109,6 +109,7 @@ struct DevScene {
 	int32_t root_bvh;        // != 0: the leaves of frame 0 are many and sit under a BVH of their own (root_walk)
 	int32_t root_bvh_root;   // its root reference
 	int32_t root_node_base;  // first float4 of its nodes in `nodes`
+	int32_t nested;          // != 0: some frame lies inside another frame than the root (enter_nested)
 	// Octants of a split root (more than 64 children, composite.cpp:125-160; n_guards == 0 otherwise).  The
 	// reference reaches a child of the root only through an octant whose bounds, and those of the octants above
 	// it, the ray enters; which occurrence that is also decides ties and how often the normal is re-normalised.
@@ -558,6 +559,35 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 	return false;
 }
 
+// A frame inside another frame - a transformed Composite below a transformed Composite, e.g. a sub-object of a loaded
+// mesh that a caller moved (composite.cpp:75-103 recurses, one bounds test and one change of coordinates per level).
+// The ray goes down the chain of frames from the root's child to `f`: at every level the reference's bounds test in
+// the space the ray has there, then the level's own inverse.  false: the ray does not get as far as the inside of `f`.
+// (`f` is the same in every lane; the chain is short, so the frame above is looked up again rather than kept)
+constexpr int kMaxNest = 8;
+template <class TC>
+__device__ __forceinline__ bool enter_nested(const DevScene& S, int f, f3 o, f3 d, f3& lo, f3& ld, TC& tc) {
+	int depth = 0;
+	for (int a = f; a > 0; a = kload(S.frames_k + a).parent) ++depth;
+	lo = o;
+	ld = d;
+	bool open = true;
+	for (int k = depth - 1; k >= 0; --k) {
+		int a = f;
+		for (int j = 0; j < k; ++j) a = kload(S.frames_k + a).parent;
+		const DevFrame F = kload(S.frames_k + a);
+		float unused;
+		tc.slab();
+		open = open && box_slab(ld3(F.bmin), ld3(F.bmax), lo, ld, unused);
+		if (!__ballot(open)) return false;
+		f3 no, nd;
+		frame_ray(S, F, a, lo, ld, no, nd, tc);
+		lo = no;
+		ld = nd;
+	}
+	return open;
+}
+
 // scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103.
 // In parts, so that the closest-hit kernel can run the mesh walks of several steps together
 // (see k_trace):
@@ -604,8 +634,9 @@ __device__ __forceinline__ bool closest_root(const DevScene& S, f3 o, f3 d, cons
 	}
 	return true;
 }
-template <class TC>
+template <bool RB, class TC>
 __device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, const RayPre& pre, TC& tc) {
+	if (RB && S.nested) return 1u;  // frames inside frames: closest_frames tests every chain itself
 	unsigned mask = S.n_frames > 32 ? 1u : 0u;
 	float unused;
 	const int nf = S.n_frames < 32 ? S.n_frames : 32;
@@ -620,6 +651,16 @@ __device__ __forceinline__ unsigned frame_mask(const DevScene& S, f3 o, f3 d, co
 template <bool KNOWN, bool RB, class TC>
 __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, const RayPre& pre, unsigned known, int* __restrict__ stk, Hit& best, TC& tc) {
 	float unused;
+	if (RB && S.nested) {  // frames inside frames: every mesh through the whole chain of frames above it
+		for (int f = 1; f < S.n_frames; ++f) {
+			const DevFrame F = kload(S.frames_k + f);
+			if (!F.has_prims) continue;
+			f3 lo, ld;
+			if (!enter_nested(S, f, o, d, lo, ld, tc)) continue;
+			bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, 0, 0);
+		}
+		return;
+	}
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
@@ -705,6 +746,12 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
 		if (!F.has_prims) continue;
+		if (RB && S.nested) {  // frames inside frames: through the whole chain of frames above the mesh
+			f3 lo, ld;
+			if (!enter_nested(S, f, o, d, lo, ld, tc)) continue;
+			if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range, tc)) return true;
+			continue;
+		}
 		tc.slab();
 		if (!box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, t)) continue;
 		if (RB && S.n_guards) {
@@ -739,9 +786,10 @@ struct ShadeTables {
 	const float4* mats;         // 4 float4 per material id
 	const float* root_winv;     // DevScene::root_winv / leaf_winv (wave-uniform)
 	const float* leaf_winv;
+	const DevFrame* frames;     // only for frames inside frames (the device table; NULL in the copies that know none)
 };
 __device__ __forceinline__ ShadeTables device_tables(const DevScene& S) {
-	return {S.root_prims, S.root_shade, S.xforms, S.frame_winv, S.frame_w, S.mat_table, S.root_winv, S.leaf_winv};
+	return {S.root_prims, S.root_shade, S.xforms, S.frame_winv, S.frame_w, S.mat_table, S.root_winv, S.leaf_winv, S.nested ? S.frames : nullptr};
 }
 
 // Rebuilds position / normal / ray_direction of the winning leaf exactly as the leaf and
@@ -763,9 +811,45 @@ __device__ __forceinline__ bool has_negative_zero(f3 v) {
 // a negative zero becomes a positive one
 __device__ __forceinline__ f3 up_position(f3 p) { return {p.x + 0.0f, p.y + 0.0f, p.z + 0.0f}; }
 
+// A triangle of a mesh that lies in a frame inside another frame (enter_nested): every level of the reference's recursion
+// spelled out.  Down: the root's inverse, then per frame of the chain the inverse of the identity once more if identity
+// Composites (sub-objects, octants) lie between it and the frame above, and the frame's own inverse; the triangle
+// reports its direction after its own inverse and the position on the ray it was handed (triangle.cpp:86).  Up: per
+// frame its transform (composite.cpp:99), and the identity's for the Composites above it.
+template <bool ORIGIN_DONE>
+__device__ __forceinline__ Surface nested_surface(const ShadeTables& T, f3 o, f3 d, const Hit& h, float4 info) {
+	Surface s;
+	int depth = 0;
+	for (int a = h.frame; a > 0; a = T.frames[a].parent) ++depth;
+	f3 lo = ORIGIN_DONE ? o : xform_point(T.root_winv, o), ld = xform_dir(T.root_winv, d);
+	for (int k = depth - 1; k >= 0; --k) {
+		int a = h.frame;
+		for (int j = 0; j < k; ++j) a = T.frames[a].parent;
+		if (k != depth - 1 && T.frames[a].levels_up > 0) {
+			lo = xform_point(T.leaf_winv, lo);
+			ld = xform_dir(T.leaf_winv, ld);
+		}
+		lo = xform_point(T.fwinv[a].m, lo);
+		ld = xform_dir(T.fwinv[a].m, ld);
+	}
+	const bool inside = ((__float_as_int(info.w) >> 16) & 0xff) != 0;
+	const f3 ldz = xform_dir(T.leaf_winv, ld);
+	f3 p = inside ? up_position(xform_point(T.leaf_winv, lo) + ldz * h.t) : lo + ld * h.t;
+	for (int a = h.frame; a > 0; a = T.frames[a].parent) {
+		p = xform_point(T.fw[a].m, p);
+		if (T.frames[a].levels_up > 0) p = up_position(p);
+	}
+	s.pos = p;
+	s.n = mk(info.x, info.y, info.z);  // constant per triangle: the whole chain applied at upload
+	s.rdir = ldz;
+	return s;
+}
+
 // ORIGIN_DONE: the origin went through the root's inverse already (the camera position, at set-up)
-template <bool ORIGIN_DONE = false>
+// GENERAL: the variant that also knows frames inside frames (the kernels of ordinary scenes carry none of that code)
+template <bool ORIGIN_DONE = false, bool GENERAL = false>
 __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, const Hit& h, float4 info) {
+	if (GENERAL && T.frames && h.frame != 0) return nested_surface<ORIGIN_DONE>(T, o, d, h, info);
 	Surface s;
 	// (all the care for the signs of zeros sits behind wave-wide tests: a sum is a negative zero only if all its
 	// terms are - an exact cancellation gives +0 - so a negative zero in a result needs one among the operands)
@@ -826,10 +910,11 @@ __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, 
 	}
 	return s;
 }
+template <bool GENERAL = false>
 __device__ __forceinline__ Surface surface_of(const DevScene& S, f3 o, f3 d, const Hit& h) {
 	float4 info = make_float4(0.f, 0.f, 0.f, 0.f);
 	if (h.frame != 0) info = S.prim_info[h.id];
-	Surface s = surface_of(device_tables(S), o, d, h, info);
+	Surface s = surface_of<false, GENERAL>(device_tables(S), o, d, h, info);
 	for (int k = 0; k < h.extra; ++k) s.n = up_one_level(s.n);  // octants of a split root above the child (composite.cpp:100)
 	return s;
 }
@@ -1506,7 +1591,7 @@ __global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 
 		RayPre pre = ray_pre(A.S, o, d);
 		const bool nan_ray = !PRIMARY && active && nan_direction(d);  // (see nan_ray_hit)
 		if (active) {
-			if (!nan_ray && closest_root<RB>(A.S, o, d, pre, stk, h, tc)) frames = frame_mask(A.S, o, d, pre, tc);
+			if (!nan_ray && closest_root<RB>(A.S, o, d, pre, stk, h, tc)) frames = frame_mask<RB>(A.S, o, d, pre, tc);
 			++cnt_trace;
 		}
 		bool park = frames != 0;
@@ -1636,7 +1721,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (I
 		fill_shade_lds(lds, A.S);
 		__syncthreads();
 	}
-	const ShadeTables T = LT ? ShadeTables{lds.prim, lds.shade, lds.xf, lds.fwinv, lds.fw, lds.mats, A.S.root_winv, A.S.leaf_winv} : device_tables(A.S);
+	const ShadeTables T = LT ? ShadeTables{lds.prim, lds.shade, lds.xf, lds.fwinv, lds.fw, lds.mats, A.S.root_winv, A.S.leaf_winv, nullptr} : device_tables(A.S);
 	ShadeStage stage;
 	{
 		float4* p = stage_mem + (threadIdx.x >> 6) * shade_stage_f4(A.stage_children, A.stage_lights);
@@ -1762,7 +1847,7 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (I
 				w = mk(ray.b.z, ray.b.w, ray.c.x);
 				pix = __float_as_uint(ray.c.y);
 			}
-			sf = surface_of<PRIMARY>(T, o, d, h, info);
+			sf = surface_of<PRIMARY, !LT>(T, o, d, h, info);
 			for (int k = 0; k < h.extra; ++k) sf.n = up_one_level(sf.n);  // octants of a split root above the child (composite.cpp:100)
 			const Material M = material_of(T, h, info);
 			bounce_terms(sf, M, w, A.last_depth != 0, A.all_children != 0, refl, refr, k1);
@@ -2025,7 +2110,7 @@ __global__ __launch_bounds__(kWalkBlock) void k_intersect(IntersectArgs A) {
 		if (A.pos || A.nrm || A.rdir) {
 			Surface sf;
 			sf.pos = sf.n = sf.rdir = mk(0, 0, 0);
-			if (hit) sf = surface_of(A.S, o, d, h);
+			if (hit) sf = surface_of<RB>(A.S, o, d, h);
 			if (A.pos) { A.pos[3 * i] = sf.pos.x; A.pos[3 * i + 1] = sf.pos.y; A.pos[3 * i + 2] = sf.pos.z; }
 			if (A.nrm) { A.nrm[3 * i] = sf.n.x; A.nrm[3 * i + 1] = sf.n.y; A.nrm[3 * i + 2] = sf.n.z; }
 			if (A.rdir) { A.rdir[3 * i] = sf.rdir.x; A.rdir[3 * i + 1] = sf.rdir.y; A.rdir[3 * i + 2] = sf.rdir.z; }

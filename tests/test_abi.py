@@ -133,7 +133,8 @@ def test_corrupted_descriptions_are_rejected_without_a_device(pt):
             cases.append((lambda d, p, f, i=i, field=field, v=v: setattr(p[i], field, v), f"prim {i}"))
     for v in (0, 256, (1 << 31) - 1):
         cases.append((lambda d, p, f, v=v: setattr(f[1], "levels_up", v), "frame 1"))
-    cases.append((lambda d, p, f: setattr(f[1], "parent", 1), "parent"))
+    cases.append((lambda d, p, f: setattr(f[1], "parent", 1), "must come earlier"))
+    cases.append((lambda d, p, f: setattr(f[1], "parent", -3), "must come earlier"))
     cases.append((lambda d, p, f: setattr(f[0], "parent", 0), "frame 0"))
     cases.append((lambda d, p, f: setattr(d, "n_prims", -5), "negative"))
     cases.append((lambda d, p, f: setattr(d, "n_lights", -1), "negative"))

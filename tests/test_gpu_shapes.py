@@ -447,3 +447,49 @@ def test_ten_thousand_samples_per_pixel_against_the_oracle(pt, port, scenes):
         assert_window_equals_oracle_samples(port, s, a["color"], w, h, aa, nb, x0, y0, 0, aa * aa)
     assert {"box1", "ball1"} <= seen and len(seen) >= 3, seen
     ds.close()
+
+
+def test_moved_parts_of_loaded_meshes(pt, port):
+    """Transformed Composites inside transformed Composites: nested.sdf loads two meshes (each a transformed
+    Composite of sub-objects), and then parts of them are moved the way a C++ caller of the reference does it,
+    root->find_child("sword")->find_child("Blade_Cube")->rotate(...) (tests/nested_ops.py).  Composite::intersect
+    recurses with one bounds test and one change of coordinates per level (composite.cpp:75-103); the parent's
+    bounds are NOT rebuilt when a child moves, so a moved part is cut off where it leaves them.  The scene description
+    carries the chain (PtxFrame::parent), the library walks it: hit identity exact, distance, position, normal and
+    ray direction bit-identical to the oracle (which tests/test_oracle.py pins to the real reference on this very
+    scene) on primary and random rays; images at the usual bar, in both pipelines (such a scene always takes the
+    staged kernels) and in the smallest work memory."""
+    from nested_ops import apply_ops
+    from oracle_lib import random_rays
+    path = pt.SDF_DIR + "/nested.sdf"
+    hs = pt.HostScene(path)
+    assert all(hs.desc.contents.frames[f].parent == 0 for f in range(1, hs.desc.contents.n_frames))   # as loaded: nothing nested
+    apply_ops(hs, None)
+    d = hs.desc.contents
+    parents = [d.frames[f].parent for f in range(d.n_frames)]
+    assert sum(1 for p in parents if p > 0) == 4 and d.n_guards == 0
+    s = port.load(path)
+    apply_ops(port, s)
+    assert hs.prim_names() == port.leaf_names(s)
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    o1, d1 = port.primary_rays(s, 240, 160, 1)
+    o2, d2 = random_rays(60000, 11, lo=(-8, -1, -20), hi=(8, 10, 4))
+    o, dd = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, dd), port.intersect(s, o, dd)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    names = np.array(hs.prim_paths())[b["rank"][m]]
+    for part in ("sword/Blade_Cube/", "sword/Guard_Cube.002/", "superhot/left_arm", "superhot/torso", "sword/Grip", "superhot/right_leg"):
+        assert sum(n.startswith(part) for n in names) > 100, part        # moved parts and parts left alone are all hit
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    ref = port.render(s, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    ds.close()
+    small = pt.DeviceScene(hs, 0, 96 << 20)
+    r = small.render_image(160, 100, 2, 4)
+    assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    small.close()
+    port.free(s)
