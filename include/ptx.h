@@ -36,7 +36,7 @@ extern "C" {
 typedef enum PtxStatus {
 	PTX_OK = 0,
 	PTX_ERR_INVALID = 1,     /* bad argument / malformed scene description            */
-	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (spheres, boxes or moved triangles inside a transformed Composite; transformed Composites more than 8 deep, or inside one another under a split root) */
+	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (a sphere, box or moved triangle below an untransformed Composite inside a transformed one; transformed Composites more than 8 deep, or inside one another under a split root) */
 	PTX_ERR_DEVICE = 3,      /* HIP call failed, or no gfx950 device                  */
 	PTX_ERR_OVERFLOW = 4,    /* a ray queue filled up: result discarded, see message  */
 	PTX_ERR_NOMEM = 5
@@ -101,6 +101,12 @@ typedef enum PtxPrimKind { PTX_SPHERE = 0, PTX_BOX = 1, PTX_TRIANGLE = 2 } PtxPr
  *   levels_in  Composites between the leaf and its frame's own transform, i.e. the
  *              octants/sub-objects above the leaf inside the frame; for frame 0 the
  *              root itself is included (so levels_in >= 1 there)
+ * Inside a frame other than the root the usual leaf is an untransformed triangle of a loaded
+ * mesh (all of a frame's go into one BVH).  A sphere, a box or a triangle with a transform of
+ * its own may live there too - a Composite a caller filled with shapes and moved as a whole, a
+ * face of a moved mesh part moved once more - if it lies directly below the frame's Composite
+ * (levels_in == 0); below an untransformed Composite in there it would be gated by bounds it may
+ * have left, which the description carries for the root only: PTX_ERR_UNSUPPORTED.
  */
 typedef struct PtxPrim {
 	int32_t kind;

@@ -899,6 +899,39 @@ void* oracle_load_scene(const char* sdf_path, const char* obj_dir) {
 	return sc.release();
 }
 void oracle_free_scene(void* s) { delete static_cast<Scene*>(s); }
+// A Composite of a caller's own with spheres and boxes in it, added to the root (composite.hpp:9-29, sphere.hpp:10, box.hpp:9):
+// kinds[i] 0 = sphere (cx cy cz r), 1 = box (min, max), 7 floats per child; names and material names joined by ';'
+int oracle_add_group(void* s, const char* name, int n, const int* kinds, const float* params, const char* child_names, const char* material_names) {
+	Scene* sc = static_cast<Scene*>(s);
+	auto split = [](std::string t) {
+		std::vector<std::string> out;
+		size_t cut;
+		while ((cut = t.find(';')) != std::string::npos) {
+			out.push_back(t.substr(0, cut));
+			t = t.substr(cut + 1);
+		}
+		out.push_back(t);
+		return out;
+	};
+	const std::vector<std::string> names = split(child_names), mats = split(material_names);
+	if ((int) names.size() != n || (int) mats.size() != n) return 1;
+	auto g = std::make_shared<Composite>(std::string(name));
+	for (int i = 0; i < n; ++i) {
+		const float* p = params + 7 * i;
+		auto it = sc->materials.find(mats[(size_t) i]);
+		if (it == sc->materials.end()) return 1;
+		if (kinds[i] == 0) g->add_child(std::make_shared<Sphere>(p[3], V3{p[0], p[1], p[2]}, names[(size_t) i], it->second));
+		else g->add_child(std::make_shared<Box>(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, names[(size_t) i], it->second));
+	}
+	g->build_octree();
+	sc->root->add_child(g);
+	sc->root->build_octree();
+	sc->rank.clear();
+	sc->leaves.clear();
+	sc->leaf_path.clear();
+	rank_leaves(*sc, *sc->root, "");
+	return 0;
+}
 // root->find_child(a)->find_child(b)...->translate / rotate / scale, as a C++ caller of the reference moves a part of a
 // loaded mesh (composite.cpp:112-114, :168-181): path levels separated by '/', op 1 translate, 2 rotate (radians), 3 scale
 int oracle_transform_child(void* s, const char* path, int op, float a, float b, float c) {

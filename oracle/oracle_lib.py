@@ -28,6 +28,22 @@ def _p(a):
 OPS = {"translate": 1, "rotate": 2, "scale": 3}
 
 
+def group_arrays(children):
+    """the arrays the three add_group entry points take (oracle, reference shim, host mirror)"""
+    kinds = np.array([0 if c[0] == "sphere" else 1 for c in children], np.int32)
+    params = np.zeros((len(children), 7), np.float32)
+    for i, c in enumerate(children):
+        params[i, :len(c[2])] = c[2]
+    return kinds, params, ";".join(c[1] for c in children).encode(), ";".join(c[3] for c in children).encode()
+
+
+def _add_group(fn, s, name, children):
+    kinds, params, names, mats = group_arrays(children)
+    fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+    if fn(s, name.encode(), len(children), _p(kinds), _p(params), names, mats) != 0:
+        raise RuntimeError("add_group failed")
+
+
 class Port:
     """oracle/cpu_ref.cpp"""
 
@@ -71,6 +87,10 @@ class Port:
 
     def free(self, s):
         self.L.oracle_free_scene(s)
+
+    def add_group(self, s, name, children):
+        """a Composite of the caller's own under the root; children: (kind 'sphere' | 'box', name, 4 or 6 floats, material name)"""
+        _add_group(self.L.oracle_add_group, s, name, children)
 
     def transform_child(self, s, path, op, a, b, c):
         """root->find_child(..)->...->translate / rotate / scale; op 'translate' | 'rotate' (radians) | 'scale'"""
@@ -196,6 +216,9 @@ class Reference:
 
     def free(self, s):
         self.L.ref_free_scene(s)
+
+    def add_group(self, s, name, children):
+        _add_group(self.L.ref_add_group, s, name, children)
 
     def transform_child(self, s, path, op, a, b, c):
         self.L.ref_transform_child.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_float, C.c_float]

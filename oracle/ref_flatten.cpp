@@ -139,7 +139,6 @@ struct Walker {
 				}
 				walk_mesh(*sub, frame, levels + 1);
 			} else {
-				if (!dynamic_cast<Triangle const*>(&s) || !is_identity(s.world_transform_)) throw std::string("non-triangle leaf inside a mesh");
 				emit_leaf(s, frame, levels);
 			}
 		}
@@ -218,6 +217,36 @@ void* ref_flatten(void* scene_ptr) {
 		out->error = e;
 	}
 	return out;
+}
+// A Composite of the caller's own with spheres and boxes in it, built with the reference's constructors and added to
+// the root (composite.hpp:9-29, sphere.hpp:10, box.hpp:9): kinds[i] 0 = sphere (cx cy cz r), 1 = box (min, max),
+// 7 floats per child; names and material names joined by ';'
+int ref_add_group(void* scene_ptr, const char* name, int n, const int* kinds, const float* params, const char* child_names, const char* material_names) {
+	Scene* scene = static_cast<Scene*>(scene_ptr);
+	auto split = [](std::string t) {
+		std::vector<std::string> out;
+		size_t cut;
+		while ((cut = t.find(';')) != std::string::npos) {
+			out.push_back(t.substr(0, cut));
+			t = t.substr(cut + 1);
+		}
+		out.push_back(t);
+		return out;
+	};
+	const std::vector<std::string> names = split(child_names), mats = split(material_names);
+	if ((int) names.size() != n || (int) mats.size() != n) return 1;
+	auto g = std::make_shared<Composite>(std::string(name));
+	for (int i = 0; i < n; ++i) {
+		const float* p = params + 7 * i;
+		auto it = scene->materials.find(mats[(size_t) i]);
+		if (it == scene->materials.end()) return 1;
+		if (kinds[i] == 0) g->add_child(std::make_shared<Sphere>(p[3], glm::vec3{p[0], p[1], p[2]}, names[(size_t) i], it->second));
+		else g->add_child(std::make_shared<Box>(glm::vec3{p[0], p[1], p[2]}, glm::vec3{p[3], p[4], p[5]}, names[(size_t) i], it->second));
+	}
+	g->build_octree();
+	scene->root->add_child(g);
+	scene->root->build_octree();
+	return 0;
 }
 // scene.root->find_child(a)->find_child(b)...->translate / rotate / scale with the reference's own methods
 // (composite.cpp:112-114, :168-181): path levels separated by '/', op 1 translate, 2 rotate (radians), 3 scale.

@@ -292,6 +292,19 @@ class HostScene:
         except Exception:
             pass
 
+    def add_group(self, name, children):
+        """What a C++ caller does to move several shapes together: a Composite of its own under the root.
+        children: (kind 'sphere' | 'box', name, (cx, cy, cz, r) | (min xyz, max xyz), material name)."""
+        kinds = np.array([0 if c[0] == "sphere" else 1 for c in children], np.int32)
+        params = np.zeros((len(children), 7), np.float32)
+        for i, c in enumerate(children):
+            params[i, :len(c[2])] = c[2]
+        self._H.pth_scene_add_group.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p]
+        if self._H.pth_scene_add_group(self.handle, name.encode(), len(children), _ptr(kinds), _ptr(params),
+                                       ";".join(c[1] for c in children).encode(), ";".join(c[3] for c in children).encode()) != 0:
+            raise RuntimeError(self._H.pth_last_error().decode())
+        self.desc = self._H.pth_scene_desc(self.handle)
+
     def transform_child(self, path, op, a, b, c):
         """What a C++ caller does after load_scene to move a part of a loaded mesh:
         root->find_child(..)->...->translate / rotate (radians) / scale; `path` = names joined by '/'.

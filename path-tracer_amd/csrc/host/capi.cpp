@@ -3,6 +3,7 @@
 // itself is include/ptx.h; nothing here computes pixels.
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "flatten.hpp"
 #include "renderer.hpp"
@@ -40,6 +41,48 @@ void* pth_load_scene(const char* sdf_path, const char* obj_dir) {
 	return nullptr;
 }
 void pth_free_scene(void* h) { delete static_cast<HostScene*>(h); }
+
+// What a C++ caller of the reference does to move several shapes together: a Composite of its own,
+//   auto g = std::make_shared<Composite>(name); g->add_child(std::make_shared<Sphere>(r, c, n, mat)); ...
+//   g->build_octree(); scene.root->add_child(g); scene.root->build_octree();
+// (framework/composite.hpp:9-29, sphere.hpp:10, box.hpp:9).  n children: kinds[i] 0 = sphere (params cx cy cz r),
+// 1 = box (params min xyz, max xyz), 7 floats per child; names and material names joined by ';'.
+int pth_scene_add_group(void* h, const char* name, int n, const int* kinds, const float* params, const char* child_names, const char* material_names) {
+	auto* hs = static_cast<HostScene*>(h);
+	try {
+		auto split = [](std::string s) {
+			std::vector<std::string> out;
+			size_t cut;
+			while ((cut = s.find(';')) != std::string::npos) {
+				out.push_back(s.substr(0, cut));
+				s = s.substr(cut + 1);
+			}
+			out.push_back(s);
+			return out;
+		};
+		const std::vector<std::string> names = split(child_names), mats = split(material_names);
+		if ((int) names.size() != n || (int) mats.size() != n) throw SceneError{"add_group: n names and n materials expected"};
+		auto g = std::make_shared<Composite>(name);
+		for (int i = 0; i < n; ++i) {
+			const float* p = params + 7 * i;
+			std::shared_ptr<Material> m = hs->scene.find_mat(mats[(size_t) i]);
+			if (kinds[i] == 0) g->add_child(std::make_shared<Sphere>(p[3], vec3{p[0], p[1], p[2]}, names[(size_t) i], m));
+			else g->add_child(std::make_shared<Box>(vec3{p[0], p[1], p[2]}, vec3{p[3], p[4], p[5]}, names[(size_t) i], m));
+		}
+		g->build_octree();
+		hs->scene.root->add_child(g);
+		hs->scene.root->build_octree();
+		hs->flat = flatten_scene(hs->scene);
+		return 0;
+	} catch (SceneError const& e) {
+		g_err = e.message;
+	} catch (const char* msg) {
+		g_err = msg;
+	} catch (std::exception const& e) {
+		g_err = e.what();
+	}
+	return 1;
+}
 
 // What a C++ caller of the reference does after load_scene to move a part of a loaded mesh:
 // scene.root->find_child(a)->find_child(b)...->translate / rotate / scale (framework/composite.cpp:112-114,

@@ -122,8 +122,8 @@ struct Walker {
 				walk_mesh(sub, frame, levels + 1, path + s.get_name() + "/", depth + 1);
 			} else {
 				++out.leaf_entries;
-				if (s.kind() != Shape::Kind::triangle || !is_identity(s.world_transform()))
-					throw SceneError{"leaf '" + s.get_name() + "': only untransformed triangles are supported inside a mesh Composite"};
+				// (a sphere, a box or a moved triangle in here is listed like any leaf; ptx_scene_create takes it when it
+				// lies directly below the frame's Composite)
 				emit_leaf(s, frame, levels, path);
 			}
 		}

@@ -459,6 +459,9 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::vector<DevXform> xforms;
 	std::vector<float4> prim_info((size_t) std::max(D->n_prims, 1));
 	std::vector<std::vector<int>> frame_tris(D->n_frames);
+	std::vector<std::vector<DevRootPrim>> frame_leaf_prims(D->n_frames);  // leaves of frames other than the root that are not plain triangles
+	std::vector<std::vector<DevRootShade>> frame_leaf_shade(D->n_frames);
+	std::vector<std::vector<DevXform>> frame_leaf_xforms(D->n_frames);
 	std::vector<char> frame_ok(D->n_frames, 1);
 	for (int f = 1; f < D->n_frames; ++f) {
 		const PtxFrame& F = D->frames[f];
@@ -481,6 +484,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 			// by the Composites above it.
 			f3 n = mk(P.normal[0], P.normal[1], P.normal[2]);
 			if (P.frame > 0) {
+				if (P.kind == PTX_TRIANGLE && !is_identity(P.world)) n = xform_dir(P.world, n);  // (a moved triangle inside a frame: its own transform first, triangle.cpp:86)
 				for (int k = 0; k < P.levels_in; ++k) n = up_one_level(n);
 				// (a frame inside a frame: the same again for every frame up the chain)
 				for (int a = P.frame; a > 0; a = D->frames[a].parent) {
@@ -542,10 +546,41 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 				root_bound.push_back(blo);
 				root_bound.push_back(bhi);
 			}
-		} else {
-			if (P.kind != PTX_TRIANGLE) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": only triangles may live inside a mesh frame");
-			if (!is_identity(P.world)) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": a mesh triangle must not carry its own transform");
+		} else if (P.kind == PTX_TRIANGLE && is_identity(P.world)) {
 			if (finite && frame_ok[P.frame]) frame_tris[P.frame].push_back(i);
+		} else {
+			// a sphere, a box or a moved triangle inside a transformed Composite: kept as a leaf of that frame (frame_leaf_t).
+			// Directly below the frame's Composite only: an untransformed Composite in between would gate the leaf with
+			// bounds it may have left, which the description does not carry for frames other than the root.
+			if (P.levels_in != 0) return fail(PTX_ERR_UNSUPPORTED, "prim " + std::to_string(i) + ": a sphere, box or moved triangle below an untransformed Composite inside a transformed one");
+			if (!finite || !frame_ok[P.frame]) continue;
+			DevRootPrim R{};
+			DevRootShade Q{};
+			DevXform X{};
+			R.kind_flags = P.kind;
+			for (int k = 0; k < 3; ++k) {
+				R.tinv[k] = P.world_inv[12 + k];
+				Q.tw[k] = P.world[12 + k];
+			}
+			std::memcpy(R.p, P.p, sizeof R.p);
+			if (P.kind == PTX_TRIANGLE)
+				for (int k = 0; k < 3; ++k) {
+					R.p[3 + k] = P.p[3 + k] - P.p[k];
+					R.p[6 + k] = P.p[6 + k] - P.p[k];
+				}
+			R.id = i;
+			R.frame = P.frame;
+			std::memcpy(X.winv, P.world_inv, sizeof X.winv);
+			std::memcpy(X.w, P.world, sizeof X.w);
+			Q.n[0] = prim_info[i].x;
+			Q.n[1] = prim_info[i].y;
+			Q.n[2] = prim_info[i].z;
+			Q.levels_in = 0;
+			Q.material = P.material;
+			frame_leaf_prims[P.frame].push_back(R);
+			frame_leaf_shade[P.frame].push_back(Q);
+			frame_leaf_xforms[P.frame].push_back(X);
+			nested = true;
 		}
 	}
 	std::vector<DevFrame> frames(D->n_frames);
@@ -647,6 +682,19 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		}
 	}
 	sc->n_nodes = (int) nodes.size();
+	// the leaves of the other frames behind the root's (a hit names a leaf by its slot in these tables)
+	const size_t n_root_leaves = root_prims.size();
+	std::vector<int2> frame_leaves(D->n_frames, make_int2(0, 0));
+	for (int f = 1; f < D->n_frames; ++f) {
+		frame_leaves[f] = make_int2((int) root_prims.size(), (int) frame_leaf_prims[f].size());
+		for (size_t k = 0; k < frame_leaf_prims[f].size(); ++k) {
+			DevRootPrim R = frame_leaf_prims[f][k];
+			R.xform = (int32_t) root_prims.size();
+			root_prims.push_back(R);
+			root_shade.push_back(frame_leaf_shade[f][k]);
+			xforms.push_back(frame_leaf_xforms[f][k]);
+		}
+	}
 
 	PtxStatus st;
 	DevScene& S = sc->dev;
@@ -658,6 +706,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		std::memcpy(&S.root_bound_k, &rb, sizeof(void*));
 	}
 	if ((st = sc->upload(xforms, &S.xforms)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
+	if ((st = sc->upload(frame_leaves, &S.frame_leaves)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(frames, &S.frames)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(frame_winv, &S.frame_winv)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
 	if ((st = sc->upload(frame_w, &S.frame_w)) != PTX_OK) { ptx_scene_destroy(sc.release()); return st; }
@@ -702,7 +751,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(&S.frames_k, &S.frames, sizeof(void*));
 	std::memcpy(&S.frame_winv_k, &S.frame_winv, sizeof(void*));
 	std::memcpy(&S.lights_k, &S.lights, sizeof(void*));
-	S.n_root_prims = (int) root_prims.size();
+	S.n_root_prims = (int) n_root_leaves;
 	S.nested = nested ? 1 : 0;
 	S.n_frames = D->n_frames;
 	S.n_lights = D->n_lights;
@@ -719,7 +768,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	for (int i = 0; i < D->n_prims && S.nan_id < 0; ++i) {
 		const PtxPrim& P = D->prims[i];
 		if (P.kind == PTX_SPHERE) continue;
-		if (P.frame == 0) {
+		if (P.frame == 0 || !(P.kind == PTX_TRIANGLE && is_identity(P.world))) {  // a leaf of the root, or a leaf kept in another frame's list
 			for (size_t k = 0; k < root_prims.size(); ++k)
 				if (root_prims[k].id == i) {
 					S.nan_id = i;
@@ -745,7 +794,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	std::memcpy(S.root_winv, D->frames[0].world_inv, sizeof S.root_winv);
 	std::memcpy(S.leaf_winv, D->frames[0].world_inv, sizeof S.leaf_winv);
 	for (int i = 0; i < D->n_prims; ++i)
-		if (D->prims[i].frame > 0) {  // an untransformed mesh triangle's own inverse (the same bits for all of them)
+		if (D->prims[i].frame > 0 && D->prims[i].kind == PTX_TRIANGLE && is_identity(D->prims[i].world)) {  // an untransformed mesh triangle's own inverse (the same bits for all of them)
 			std::memcpy(S.leaf_winv, D->prims[i].world_inv, sizeof S.leaf_winv);
 			break;
 		}

@@ -54,8 +54,8 @@ struct DevRootPrim {  // a leaf of frame 0, tested by every ray: 64 B, fetched w
 	int32_t kind_flags;  // PtxPrimKind | kPlain
 	float p[9];          // sphere: c, r | box: lo, hi | triangle: v0, e1, e2
 	int32_t id;
-	int32_t xform;       // index into DevScene::xforms (= the leaf's own slot: one entry per frame-0 leaf)
-	int32_t pad;
+	int32_t xform;       // index into DevScene::xforms (= the leaf's own slot: one entry per leaf)
+	int32_t frame;       // 0: a leaf of the root; else the frame the leaf lies in (records behind the n_root_prims leaves of the root)
 };
 struct DevXform {  // full matrices of a leaf whose transform rotates or scales
 	float winv[16];
@@ -109,7 +109,8 @@ struct DevScene {
 	int32_t root_bvh;        // != 0: the leaves of frame 0 are many and sit under a BVH of their own (root_walk)
 	int32_t root_bvh_root;   // its root reference
 	int32_t root_node_base;  // first float4 of its nodes in `nodes`
-	int32_t nested;          // != 0: some frame lies inside another frame than the root (enter_nested)
+	int32_t nested;          // != 0: some frame lies inside another frame than the root, or holds leaves other than plain triangles (enter_nested)
+	const int2* frame_leaves;  // per frame: (first, count) of its leaves that are not plain triangles, in root_prims / root_shade / xforms behind the root's
 	// Octants of a split root (more than 64 children, composite.cpp:125-160; n_guards == 0 otherwise).  The
 	// reference reaches a child of the root only through an octant whose bounds, and those of the octants above
 	// it, the ray enters; which occurrence that is also decides ties and how often the normal is re-normalised.
@@ -588,6 +589,30 @@ __device__ __forceinline__ bool enter_nested(const DevScene& S, int f, f3 o, f3 
 	return open;
 }
 
+// A sphere, a box or a moved triangle that lies directly in a frame other than the root (a group of shapes a caller
+// built and moved; a face of a moved mesh part moved once more): the reference's per-shape intersect on the ray as
+// it is inside that frame, through the leaf's own inverse (shape.cpp:50-52; sphere.cpp:35-46, box.cpp:89-165,
+// triangle.cpp:56-85).  Leaf `slot` of root_prims, chosen per frame (the same in every lane).
+template <class TC>
+__device__ __forceinline__ bool frame_leaf_t(const DevScene& S, int slot, f3 o, f3 d, float& t, int& id, TC& tc) {
+	const DevRootPrim P = kload(S.root_prims_k + slot);
+	const Mat16 Wi = kload(reinterpret_cast<PTX_KPTR(Mat16)>(S.xforms_k + slot));
+	const int kind = P.kind_flags & 0xff;
+	id = P.id;
+	const f3 lo = xform_point(Wi.m, o), ld = xform_dir(Wi.m, d);
+	tc.xform();
+	if (kind == PTX_SPHERE) {
+		tc.sphere();
+		return sphere_t(ld3(P.p), P.p[3], lo, ld, t);
+	}
+	if (kind == PTX_BOX) {
+		tc.box();
+		return box_slab(ld3(P.p), ld3(P.p + 3), lo, ld, t);
+	}
+	tc.tri();
+	return tri_t(ld3(P.p), ld3(P.p + 3), ld3(P.p + 6), lo, ld, t);
+}
+
 // scene.root->intersect(ray): Composite::intersect of the root, framework/composite.cpp:75-103.
 // In parts, so that the closest-hit kernel can run the mesh walks of several steps together
 // (see k_trace):
@@ -654,10 +679,22 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 	if (RB && S.nested) {  // frames inside frames: every mesh through the whole chain of frames above it
 		for (int f = 1; f < S.n_frames; ++f) {
 			const DevFrame F = kload(S.frames_k + f);
-			if (!F.has_prims) continue;
+			const int2 leaves = S.frame_leaves[f];
+			if (!F.has_prims && !leaves.y) continue;
 			f3 lo, ld;
 			if (!enter_nested(S, f, o, d, lo, ld, tc)) continue;
-			bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, 0, 0);
+			for (int j = leaves.x; j < leaves.x + leaves.y; ++j) {
+				float t;
+				int id;
+				if (frame_leaf_t(S, j, lo, ld, t, id, tc) && (t < best.t || (t == best.t && id < best.id))) {
+					best.t = t;
+					best.id = id;
+					best.frame = 0;  // (a leaf is named by its slot, like a leaf of the root)
+					best.slot = j;
+					best.extra = 0;
+				}
+			}
+			if (F.has_prims) bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, 0, 0);
 		}
 		return;
 	}
@@ -745,13 +782,22 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 	}
 	for (int f = 1; f < S.n_frames; ++f) {
 		const DevFrame F = kload(S.frames_k + f);
-		if (!F.has_prims) continue;
 		if (RB && S.nested) {  // frames inside frames: through the whole chain of frames above the mesh
+			const int2 leaves = S.frame_leaves[f];
+			if (!F.has_prims && !leaves.y) continue;
 			f3 lo, ld;
 			if (!enter_nested(S, f, o, d, lo, ld, tc)) continue;
-			if (bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range, tc)) return true;
+			bool found = false;
+			for (int j = leaves.x; j < leaves.x + leaves.y; ++j) {
+				float tl;
+				int id;
+				found = found || (frame_leaf_t(S, j, lo, ld, tl, id, tc) && tl <= range);
+			}
+			if (found) return true;
+			if (F.has_prims && bvh_walk<true>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, dummy, range, tc)) return true;
 			continue;
 		}
+		if (!F.has_prims) continue;
 		tc.slab();
 		if (!box_test(ld3(F.bmin), ld3(F.bmax), o, d, pre, t)) continue;
 		if (RB && S.n_guards) {
@@ -845,11 +891,65 @@ __device__ __forceinline__ Surface nested_surface(const ShadeTables& T, f3 o, f3
 	return s;
 }
 
+// The same for a sphere, a box or a moved triangle that lies directly in a frame other than the root (frame_leaf_t).
+template <bool ORIGIN_DONE>
+__device__ __forceinline__ Surface nested_leaf_surface(const ShadeTables& T, f3 o, f3 d, const Hit& h) {
+	Surface s;
+	const DevRootPrim& P = T.prim[h.slot];
+	const DevRootShade& Q = T.shade[h.slot];
+	const DevXform& X = T.xf[h.slot];
+	const int frame = P.frame, kind = P.kind_flags & 0xff;
+	int depth = 0;
+	for (int a = frame; a > 0; a = T.frames[a].parent) ++depth;
+	f3 fo = ORIGIN_DONE ? o : xform_point(T.root_winv, o), fd = xform_dir(T.root_winv, d);
+	for (int k = depth - 1; k >= 0; --k) {
+		int a = frame;
+		for (int j = 0; j < k; ++j) a = T.frames[a].parent;
+		if (k != depth - 1 && T.frames[a].levels_up > 0) {
+			fo = xform_point(T.leaf_winv, fo);
+			fd = xform_dir(T.leaf_winv, fd);
+		}
+		fo = xform_point(T.fwinv[a].m, fo);
+		fd = xform_dir(T.fwinv[a].m, fd);
+	}
+	// the leaf, on the ray as it is inside its frame (as surface_of does it for a leaf of the root)
+	const f3 lo = xform_point(X.winv, fo), ld = xform_dir(X.winv, fd);
+	f3 p, n;
+	if (kind == PTX_TRIANGLE) {
+		p = fo + fd * h.t;
+		s.rdir = ld;
+		n = ld3(Q.n);  // constant per triangle: the whole chain applied at upload
+	} else {
+		if (kind == PTX_SPHERE) {
+			p = xform_point(X.w, lo + ld * h.t);
+			n = normalize(p - xform_point(X.w, ld3(P.p)));
+		} else {
+			n = normalize(xform_dir(X.w, box_face_normal(ld3(P.p), ld3(P.p + 3), lo + ld * h.t)));
+			p = fo + fd * h.t;
+		}
+		s.rdir = fd;
+	}
+	for (int a = frame; a > 0; a = T.frames[a].parent) {
+		p = xform_point(T.fw[a].m, p);
+		if (kind != PTX_TRIANGLE) n = normalize(xform_dir(T.fw[a].m, n));
+		const int up = T.frames[a].levels_up;
+		if (up > 0) p = up_position(p);
+		if (kind != PTX_TRIANGLE)
+			for (int k = 0; k < up; ++k) n = up_one_level(n);
+	}
+	s.pos = p;
+	s.n = n;
+	return s;
+}
+
 // ORIGIN_DONE: the origin went through the root's inverse already (the camera position, at set-up)
 // GENERAL: the variant that also knows frames inside frames (the kernels of ordinary scenes carry none of that code)
 template <bool ORIGIN_DONE = false, bool GENERAL = false>
 __device__ __forceinline__ Surface surface_of(const ShadeTables& T, f3 o, f3 d, const Hit& h, float4 info) {
-	if (GENERAL && T.frames && h.frame != 0) return nested_surface<ORIGIN_DONE>(T, o, d, h, info);
+	if (GENERAL && T.frames) {
+		if (h.frame != 0) return nested_surface<ORIGIN_DONE>(T, o, d, h, info);
+		if (T.prim[h.slot].frame != 0) return nested_leaf_surface<ORIGIN_DONE>(T, o, d, h);
+	}
 	Surface s;
 	// (all the care for the signs of zeros sits behind wave-wide tests: a sum is a negative zero only if all its
 	// terms are - an exact cancellation gives +0 - so a negative zero in a result needs one among the operands)

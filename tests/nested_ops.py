@@ -18,3 +18,30 @@ def apply_ops(impl, scene, ops=NESTED_OPS):
             impl.transform_child(path, op, a, b, c)
         else:
             impl.transform_child(scene, path, op, a, b, c)
+
+
+# A Composite of the caller's own (spheres and boxes in it) added to the root and moved as a whole, members of it moved
+# once more inside it, and single faces of a mesh part that was itself moved: leaves that are not plain triangles inside
+# transformed Composites.
+GROUP = ("grp", [("sphere", "gs1", (0.0, 0.0, 0.0, 0.8), "glass"), ("box", "gb1", (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), "red"),
+                 ("sphere", "gs2", (1.5, 0.3, 0.0, 0.5), "mirror"), ("box", "gb2", (1.0, -0.8, -0.4, 2.2, -0.3, 0.4), "white")])
+GROUP_OPS = [
+    ("grp/gs2", "translate", 0.0, 0.5, 0.2),
+    ("grp/gb1", "rotate", 0.5, 0.3, 0.0),
+    ("grp/gb2", "scale", 1.0, 1.5, 1.0),
+    ("grp", "translate", 0.5, 4.5, -10.0),
+    ("grp", "rotate", 0.4, 0.2, 0.1),
+    ("grp", "scale", 1.2, 0.9, 1.1),
+    ("sword/Blade_Cube/face60", "translate", 0.3, 0.0, 0.0),
+    ("sword/Blade_Cube/face61", "rotate", 0.0, 0.0, 0.3),
+]
+
+
+def apply_group(impl, scene):
+    """NESTED_OPS, then the group and GROUP_OPS"""
+    apply_ops(impl, scene)
+    if scene is None:
+        impl.add_group(*GROUP)
+    else:
+        impl.add_group(scene, *GROUP)
+    apply_ops(impl, scene, GROUP_OPS)

@@ -493,3 +493,44 @@ def test_moved_parts_of_loaded_meshes(pt, port):
     assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
     small.close()
     port.free(s)
+
+
+def test_shapes_grouped_and_moved_together(pt, port):
+    """Leaves that are not plain triangles inside transformed Composites: on top of the moved mesh parts of
+    test_moved_parts_of_loaded_meshes, a Composite of the caller's own with two spheres and two boxes is added to the
+    root and moved as a whole (translate, rotate, uneven scale), its members are moved once more inside it, and two
+    faces of the sword's blade - itself a moved part of a moved mesh - are moved on their own (tests/nested_ops.py).
+    Every such leaf is reached through the chain of frames above it and its own inverse, and reports position,
+    normal and ray direction as Sphere / Box / Triangle::intersect and the Composites above would: hit identity exact,
+    distance, position, normal, ray direction bit-identical to the oracle (pinned to the real reference on this scene
+    by tests/test_oracle.py), images at the usual bar."""
+    from nested_ops import apply_group
+    from oracle_lib import random_rays
+    path = pt.SDF_DIR + "/nested.sdf"
+    hs = pt.HostScene(path)
+    apply_group(hs, None)
+    s = port.load(path)
+    apply_group(port, s)
+    assert hs.prim_names() == port.leaf_names(s)
+    d = hs.desc.contents
+    inside = [i for i in range(d.n_prims) if d.prims[i].frame > 0 and (d.prims[i].kind != 2 or any(d.prims[i].world[k] != (1.0 if k % 5 == 0 else 0.0) for k in range(16)))]
+    assert len(inside) == 6 and {d.prims[i].kind for i in inside} == {0, 1, 2}
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    o1, d1 = port.primary_rays(s, 240, 160, 1)
+    o2, d2 = random_rays(60000, 11, lo=(-8, -1, -20), hi=(8, 10, 4))
+    o, dd = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, dd), port.intersect(s, o, dd)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    paths = np.array(hs.prim_paths())[b["rank"][m]]
+    for leaf in ("grp/gs1", "grp/gs2", "grp/gb1", "grp/gb2"):
+        assert (paths == leaf).sum() > 30, leaf
+    assert np.isin(paths, ["sword/Blade_Cube/face60", "sword/Blade_Cube/face61"]).sum() > 20
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    ref = port.render(s, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    ds.close()
+    port.free(s)

@@ -185,17 +185,22 @@ def test_oracle_equals_reference_on_hand_written_fixtures(port, tmp_path, name):
     assert np.array_equal(ia["rgb"], ib["rgb"]) and same_bits_or_both_nan(ia["color"], ib["color"])
 
 
-def test_oracle_equals_reference_on_moved_mesh_parts(port):
+@pytest.mark.parametrize("grouped", [False, True])
+def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     """nested.sdf with parts of its two loaded meshes moved after load_scene (tests/nested_ops.py:
     root->find_child(..)->find_child(..)->translate / rotate / scale with the reference's own methods):
     transformed Composites inside transformed Composites.  Reference and oracle: the same hit object,
     bit-identical distance, position, normal and ray direction on primary and random rays, a bit-identical image;
     and the scene hand-over written against the reference's classes equals the host mirror's byte for byte, with
-    the chain of frames in it.  Container-only (needs oracle/_ref/libref.so)."""
+    the chain of frames in it.  grouped: in addition a Composite of the caller's own with spheres and boxes in it, moved as
+    a whole and member by member, and single faces of a moved mesh part moved once more (leaves that are not plain
+    triangles inside transformed Composites).  Container-only (needs oracle/_ref/libref.so)."""
     import importlib
     import sys
     from conftest import REPO
-    from nested_ops import apply_ops
+    from nested_ops import apply_group, apply_ops
+    if grouped:
+        apply_ops = apply_group     # noqa: F811
     from oracle_lib import Reference, SDF_DIR, random_rays
     if not Reference.available():
         pytest.skip("oracle/_ref/libref.so absent")
@@ -228,4 +233,4 @@ def test_oracle_equals_reference_on_moved_mesh_parts(port):
         assert rp[part] == mp[part], part
     assert rn == mn
     d = hs.desc.contents
-    assert sorted(d.frames[f].parent for f in range(d.n_frames)) == [-1, 0, 0, 1, 1, 4, 4]
+    assert sorted(d.frames[f].parent for f in range(d.n_frames)) == ([-1, 0, 0, 0, 2, 2, 5, 5] if grouped else [-1, 0, 0, 1, 1, 4, 4])
