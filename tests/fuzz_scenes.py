@@ -4,7 +4,8 @@ BVH over the frame-0 leaves) or more than 64 (a root the reference splits into o
 them translated, rotated (also by exact quarter turns, whose matrices carry exact and negative
 zeros) and scaled (also unevenly), sometimes a mesh from the fixtures, an enclosing room or not,
 none to five lights, materials of every shading case (Phong only, mirror, glass, both).
-The same text goes to the reference build, to the CPU oracle and to the product."""
+The same text goes to the reference build, to the CPU oracle and to the product.  Some scenes are changed after
+loading the way a C++ caller changes them (scene_moves: parts of a mesh moved, a Composite of the caller's own)."""
 import numpy as np
 
 f32 = np.float32
@@ -114,6 +115,74 @@ def scene_text(seed):
     return "\n".join(lines + tf) + "\n"
 
 
+PARTS = {"sword": ("Grip_Cube.004", "Guard_Cube.002", "Pommel_Cube.003", "Blade_Cube"),
+         "superhot": ("torso_Superhot_Enemy_Stl.002", "right_leg_Superhot_Enemy_Stl.003", "left_leg_Superhot_Enemy_Stl.004",
+                      "left_arm_Superhot_Enemy_Stl.005", "right_arm_Superhot_Enemy_Stl.006", "head_Superhot_Enemy_Stl.007")}
+
+
+def scene_moves(seed):
+    """What a C++ caller does to some of the scenes after load_scene (None for the others): parts of the loaded mesh moved
+    through find_child(..)->find_child(..)->translate / rotate / scale - transformed Composites inside a transformed
+    Composite -, in some scenes a face of a moved part moved once more and a Composite of the caller's own with spheres
+    and boxes in it, moved as a whole and member by member.  Returns (ops, group, group_ops): ops as
+    (path, 'translate' | 'rotate' | 'scale', a, b, c), group as (name, [(kind, name, numbers, material)])."""
+    n = N_SHAPES[seed % len(N_SHAPES)]
+    if seed % 2 or not (seed % 4 == 0 or seed % 8 == 2) or n > 30:
+        return None     # no mesh, left as loaded, or a root the reference splits (frames inside frames are not taken under a split root)
+    rng = np.random.default_rng(5000 + seed)
+    S = scene_scale(seed)
+    mesh = MESHES[(seed // 2) % len(MESHES)]
+    parts = list(PARTS[mesh])
+    ops = []
+    for k in rng.choice(len(parts), size=2 if mesh == "sword" else 3, replace=False):
+        path = f"{mesh}/{parts[int(k)]}"
+        for _ in range(int(rng.integers(1, 4))):
+            op = ("translate", "rotate", "scale")[int(rng.integers(0, 3))]
+            if op == "translate":
+                ops.append((path, op, *(float(v) for v in rng.uniform(-0.6, 0.6, 3))))
+            elif op == "rotate":
+                ops.append((path, op, *(float(v) for v in rng.uniform(-0.7, 0.7, 3))))
+            else:
+                ops.append((path, op, *(float(v) for v in rng.uniform(0.6, 1.6, 3))))
+    if mesh == "sword" and any(o[0].endswith("Blade_Cube") for o in ops):
+        ops.append(("sword/Blade_Cube/face60", "translate", 0.2, 0.1, 0.0))
+        ops.append(("sword/Blade_Cube/face55", "rotate", 0.0, 0.3, 0.2))
+    group, group_ops = None, []
+    if seed % 8 in (2, 4):
+        kids = []
+        for k in range(int(rng.integers(2, 5))):
+            c = rng.uniform(-1.5, 1.5, 3) * S
+            if rng.random() < 0.5:
+                kids.append(("sphere", f"gs{k}", (float(c[0]), float(c[1]), float(c[2]), float(rng.uniform(0.3, 0.9) * S)), f"m{int(rng.integers(0, 6))}"))
+            else:
+                e = rng.uniform(0.2, 0.8, 3) * S
+                kids.append(("box", f"gb{k}", tuple(float(v) for v in (*(c - e), *(c + e))), f"m{int(rng.integers(0, 6))}"))
+        group = ("grp", kids)
+        group_ops.append((f"grp/{kids[0][1]}", "translate", *(float(v) for v in rng.uniform(-0.5, 0.5, 3) * S)))
+        group_ops.append((f"grp/{kids[-1][1]}", "rotate", *(float(v) for v in rng.uniform(-0.8, 0.8, 3))))
+        group_ops.append(("grp", "translate", float(rng.uniform(-4, 4) * S), float(rng.uniform(-2, 2) * S), float(rng.uniform(-14, -7) * S)))
+        group_ops.append(("grp", "rotate", *(float(v) for v in rng.uniform(-1.0, 1.0, 3))))
+        group_ops.append(("grp", "scale", *(float(v) for v in rng.uniform(0.7, 1.5, 3))))
+    return ops, group, group_ops
+
+
+def apply_moves(impl, scene, seed):
+    """scene_moves(seed) applied through oracle_lib.Port / Reference (scene = their handle) or a path-tracer_amd HostScene
+    (scene = None); returns whether the scene has any"""
+    moves = scene_moves(seed)
+    if moves is None:
+        return False
+    ops, group, group_ops = moves
+    args = () if scene is None else (scene,)
+    for path, op, a, b, c in ops:
+        impl.transform_child(*args, path, op, a, b, c)
+    if group:
+        impl.add_group(*args, *group)
+    for path, op, a, b, c in group_ops:
+        impl.transform_child(*args, path, op, a, b, c)
+    return True
+
+
 def rays(seed, n_random=12000, n_axis=3000):
     """Random rays through the region of the shapes, and rays with one or two direction components
     exactly zero (the branch of the box test for rays parallel to a slab, the divisions by zero
@@ -166,6 +235,7 @@ def full_size_findings(pt, seed, folder, W=1920, H=1080, AA=4):
     of the queue driving under load.  Returns the findings as text lines."""
     sdf, obj_dir = write_scene(seed, folder, pt.SDF_DIR)
     hs = pt.HostScene(sdf, obj_dir)
+    nested = apply_moves(hs, None, seed)
     nb = (4, 6, 8)[seed % 3]
     big, tiny = pt.DeviceScene(hs, 0, 1 << 32), pt.DeviceScene(hs, 0, 1)
     found = []
@@ -174,8 +244,8 @@ def full_size_findings(pt, seed, folder, W=1920, H=1080, AA=4):
         fin = np.isfinite(ref["color"]).all(axis=2)
         rb = ref["color"].astype(np.float64)
         for ds, name, pipeline in ((big, "ample", "fused"), (tiny, "smallest", "staged"), (tiny, "smallest", "fused")):
-            if pipeline == "fused" and hs.desc.contents.n_guards:
-                continue        # (a split root always takes the staged kernels)
+            if pipeline == "fused" and (hs.desc.contents.n_guards or nested):
+                continue        # (a split root always takes the staged kernels, and so do frames inside frames)
             q = ds.render_image(W, H, AA, nb, pipeline=pipeline)
             same = all(q["stats"][k] == ref["stats"][k] for k in ("trace_rays", "shadow_rays", "shaded_hits", "per_depth_rays"))
             odd = np.isfinite(q["color"]).all(axis=2) != fin

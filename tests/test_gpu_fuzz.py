@@ -3,7 +3,9 @@
 Eighteen scenes: 3 to 130 spheres, boxes and triangles under the root (the leaf list, the BVH over
 the frame-0 leaves, roots the reference splits into octants), random and quarter-turn rotations,
 even and uneven scales, meshes with turned and unevenly scaled transforms, with and without an
-enclosing room, none to five lights, every shading case, four in fourteen scaled by 100, 10^4, 10^-2 or 10^-3.  The CPU oracle is checked against the
+enclosing room, none to five lights, every shading case, four in fourteen scaled by 100, 10^4, 10^-2 or 10^-3; in five of them parts of
+the mesh are moved after loading (transformed Composites inside a transformed Composite), in three a Composite of the
+caller's own with spheres and boxes in it is added and moved.  The CPU oracle is checked against the
 real reference on these very scenes in tests/test_oracle.py
 (test_oracle_equals_reference_on_generated_scenes); here the device must give the oracle's
 answers: hit identity exact, t / position / normal / ray_direction bit-identical - on primary
@@ -22,11 +24,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PTX_FUZZ_FIRST", "0")), int(os.environ.get("PTX_FUZZ_FIRST", "0")) + int(os.environ.get("PTX_FUZZ_SEEDS", "18"))))   # (PTX_FUZZ_FIRST / PTX_FUZZ_SEEDS: a longer sweep)
 def test_generated_scene(pt, port, tmp_path, seed):
-    from fuzz_scenes import rays, same_bits_or_both_nan, write_scene
+    from fuzz_scenes import apply_moves, rays, same_bits_or_both_nan, write_scene
     sdf, obj_dir = write_scene(seed, tmp_path, pt.SDF_DIR)
     hs = pt.HostScene(sdf, obj_dir)
+    apply_moves(hs, None, seed)     # (some scenes: parts of the mesh moved after loading, a Composite of the caller's own)
     ds = pt.DeviceScene(hs, 0, 1 << 28)
     s = port.load(sdf, obj_dir)
+    apply_moves(port, s, seed)
     assert hs.prim_paths() == port.leaf_paths(s)
     o1, d1 = port.primary_rays(s, 120, 80, 1)
     o2, d2 = rays(seed)

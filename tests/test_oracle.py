@@ -131,7 +131,7 @@ def test_oracle_equals_reference_on_generated_scenes(port, tmp_path, seed):
     position, normal and ray direction on primary rays, random rays and rays with zero direction
     components, and a bit-identical small image.  Container-only (needs oracle/_ref/libref.so); it
     is what makes the oracle a pinned checker on these scenes too."""
-    from fuzz_scenes import rays, same_bits_or_both_nan, write_scene
+    from fuzz_scenes import apply_moves, rays, same_bits_or_both_nan, write_scene
     from oracle_lib import Reference
     if not Reference.available():
         pytest.skip("oracle/_ref/libref.so absent")
@@ -139,6 +139,8 @@ def test_oracle_equals_reference_on_generated_scenes(port, tmp_path, seed):
     from oracle_lib import SDF_DIR
     sdf, obj_dir = write_scene(seed, tmp_path, SDF_DIR)
     s, r = port.load(sdf, obj_dir), ref.load(sdf)
+    apply_moves(port, s, seed)      # (some scenes: parts of the mesh moved after loading, a Composite of the caller's own)
+    apply_moves(ref, r, seed)
     leaf = port.leaf_names(s)
     o1, d1 = port.primary_rays(s, 60, 40, 1)
     o2, d2 = rays(seed, 4000, 1500)
