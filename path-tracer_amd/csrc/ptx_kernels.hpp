@@ -39,7 +39,7 @@ constexpr unsigned kMaxBounces = 63;
 // 75.9, primary closest hit 35.8 -> 34.0; the closest-hit kernel of the deeper depths, whose waves walk their parked
 // rays once more at their end, 85.1 -> 88.1), 65 536 segments 306.
 constexpr unsigned kMaxSeg = PTX_MAX_SEG;
-constexpr size_t count_bytes(unsigned max_seg) { return ((size_t) 3 * (kMaxBounces + 2) + 1) * max_seg * sizeof(unsigned); }  // per depth: ray, shadow-ray and hit counts of every segment; one more row: the order the segments of a depth are taken in
+constexpr size_t count_bytes(unsigned max_seg) { return ((size_t) 3 * (kMaxBounces + 2) + 1) * max_seg * sizeof(unsigned); }  // per depth: ray, shadow-ray and hit counts of every segment; one more row: the order the segments of the depths > 0 are taken in
 
 // ---------------------------------------------------------------------------
 // device scene
@@ -2149,40 +2149,85 @@ __global__ __launch_bounds__(kWalkBlock, PTX_SHADOW_WAVES) void k_shadow(BounceA
 #undef A
 }
 
-// order[] = the segments of one depth sorted by the number of 64-record steps a launch takes of them, most first (a
-// counting sort in one workgroup: n_seg is some thousand).  Segments with equal step counts come in any order: the
+// order[] = the segments of one depth sorted by the number of 64-record steps a launch takes of them, most first: a
+// counting sort in ONE workgroup (n_seg is some ten thousand).  Every thread reads all its segments' counts at once,
+// every wave counts into bins of its own in LDS and the places of a bin go to the waves in turn.  It takes 57 us for
+// 32 768 segments - the lanes of a wave mostly hold the same few step counts and queue for the same words of LDS, on the
+// one compute unit the workgroup runs on -, so it is made once per chunk of primary samples, in a stream of the scene's
+// own beside the shadow kernel of depth 0 (render_accumulate).  Segments with equal step counts come in any order: the
 // order decides when a segment is worked on, never what is computed.
+//   (tried instead: the waves of the shading kernel, which know the counts first, count their segments into the bins
+//   with one global atomic each, and a kernel of many workgroups places them: the 32 768 atomics of a launch fall on a
+//   handful of cache lines - most segments hold about the same - and cost the shading kernel 4 ms per depth.)
 constexpr int kOrderBlock = 1024;
-constexpr int kOrderBins = 256;
+constexpr int kOrderBins = 128;
+constexpr int kOrderPer = (int) (kMaxSeg / kOrderBlock) > 0 ? (int) (kMaxSeg / kOrderBlock) : 1;  // segments per thread
+static_assert(kMaxSeg % kOrderBlock == 0 || kMaxSeg < (unsigned) kOrderBlock, "k_order: segments per thread");
 __global__ __launch_bounds__(kOrderBlock) void k_order(const unsigned* __restrict__ count, unsigned n_seg, unsigned seg_cap, unsigned first, unsigned take,
                                                        unsigned* __restrict__ order) {
-	__shared__ unsigned bin[kOrderBins];
-	__shared__ unsigned start[kOrderBins];
+	constexpr int kWaves = kOrderBlock / 64;
+	__shared__ unsigned bin[kWaves][kOrderBins];  // per wave: segments per bin, then the first place of the wave's share of the bin
+	__shared__ unsigned total[kOrderBins];
+	const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63u;
 	const unsigned max_steps = (seg_cap + 63) / 64;
-	auto key_of = [&](unsigned seg) {
-		const unsigned steps = (taken(count[seg], seg_cap, first, take) + 63) >> 6;
-		const unsigned k = max_steps < (unsigned) kOrderBins ? steps : (unsigned) ((unsigned long long) steps * (kOrderBins - 1) / max_steps);
-		return (unsigned) (kOrderBins - 1) - min(k, (unsigned) (kOrderBins - 1));  // most steps first
-	};
-	for (unsigned i = threadIdx.x; i < (unsigned) kOrderBins; i += kOrderBlock) bin[i] = 0;
+	unsigned raw[kOrderPer];
+#pragma unroll
+	for (int k = 0; k < kOrderPer; ++k) {
+		const unsigned s = (unsigned) k * kOrderBlock + t;
+		raw[k] = count[s < n_seg ? s : 0u];
+	}
+	for (unsigned i = t; i < (unsigned) (kWaves * kOrderBins); i += kOrderBlock) (&bin[0][0])[i] = 0;
 	__syncthreads();
-	for (unsigned s = threadIdx.x; s < n_seg; s += kOrderBlock) atomicAdd(&bin[key_of(s)], 1u);
-	__syncthreads();
-	if (threadIdx.x < 64) {  // exclusive prefix sums of the bins: four bins per lane, then across the lanes
-		const unsigned b0 = bin[4 * threadIdx.x], b1 = bin[4 * threadIdx.x + 1], b2 = bin[4 * threadIdx.x + 2], b3 = bin[4 * threadIdx.x + 3];
-		unsigned sum = b0 + b1 + b2 + b3, incl = sum;
-		for (int off = 1; off < 64; off <<= 1) {
-			const unsigned o = __shfl_up(incl, off);
-			if ((int) threadIdx.x >= off) incl += o;
-		}
-		const unsigned excl = incl - sum;
-		start[4 * threadIdx.x] = excl;
-		start[4 * threadIdx.x + 1] = excl + b0;
-		start[4 * threadIdx.x + 2] = excl + b0 + b1;
-		start[4 * threadIdx.x + 3] = excl + b0 + b1 + b2;
+	unsigned key[kOrderPer];
+#pragma unroll
+	for (int k = 0; k < kOrderPer; ++k) {
+		const unsigned steps = (taken(raw[k], seg_cap, first, take) + 63) >> 6;
+		const unsigned q = max_steps < (unsigned) kOrderBins ? steps : (unsigned) ((unsigned long long) steps * (kOrderBins - 1) / max_steps);
+		key[k] = (unsigned) (kOrderBins - 1) - min(q, (unsigned) (kOrderBins - 1));  // most steps first
+		if ((unsigned) k * kOrderBlock + t < n_seg) atomicAdd(&bin[w][key[k]], 1u);
 	}
 	__syncthreads();
-	for (unsigned s = threadIdx.x; s < n_seg; s += kOrderBlock) order[atomicAdd(&start[key_of(s)], 1u)] = s;
+	if (t < (unsigned) kOrderBins) {  // a bin's segments over all waves ...
+		unsigned sum = 0;
+		for (int v = 0; v < kWaves; ++v) sum += bin[v][t];
+		total[t] = sum;
+	}
+	__syncthreads();
+	if (t < 64) {  // ... the bins' first places (kOrderBins / 64 bins per lane, then across the lanes) ...
+		constexpr int kPer = kOrderBins / 64;
+		unsigned v[kPer], mine = 0;
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			v[k] = total[t * kPer + k];
+			mine += v[k];
+		}
+		unsigned incl = mine;
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned o = __shfl_up(incl, off);
+			if ((int) lane >= off) incl += o;
+		}
+		unsigned at = incl - mine;
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			total[t * kPer + k] = at;
+			at += v[k];
+		}
+	}
+	__syncthreads();
+	if (t < (unsigned) kOrderBins) {  // ... and every wave's share of a bin
+		unsigned at = total[t];
+		for (int v = 0; v < kWaves; ++v) {
+			const unsigned c = bin[v][t];
+			bin[v][t] = at;
+			at += c;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < kOrderPer; ++k) {
+		const unsigned s = (unsigned) k * kOrderBlock + t;
+		if (s < n_seg) order[atomicAdd(&bin[w][key[k]], 1u)] = s;
+	}
 }
 
 // sums the statistic slots of one depth into the compact block the host reads
