@@ -278,7 +278,9 @@ void ptx_trim(void);
 /*
  * Adds, for every pixel, the sum over the selected samples of trace(primary ray)
  * (framework/renderer.cpp:74-85) to d_accum (w*h*3 floats, row-major, y up, NOT cleared
- * here).  All device work goes to `stream`.  The sums of one call are formed in doubles in a
+ * here).  All device work goes to `stream` (one small kernel per chunk of primary samples runs in a
+ * stream of the scene's own, between two events that tie it into `stream`: work queued on `stream`
+ * behind the call is behind it as well).  The sums of one call are formed in doubles in a
  * buffer of the scene's own (allocated at the first call, grown with the image size) and added to
  * d_accum once per pixel at the end of the call.  Host waits on the stream: none while rendering
  * when no material of the scene spawns two child rays; with such materials one per chunk of

@@ -976,7 +976,10 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	unsigned* const order = M.counts + (size_t) 3 * (kMaxBounces + 2) * M.max_seg;
 	// the stream in which k_order runs beside the shadow kernel (not where the library may create nothing)
 	if (may_create_events && !sc->side) {
-		if (hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking) != hipSuccess) sc->side = nullptr;
+		// (the highest priority there is: its one workgroup competes with the shadow kernel's thousands for a compute unit)
+		int least = 0, greatest = 0;
+		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+		if (hipStreamCreateWithPriority(&sc->side, hipStreamNonBlocking, greatest) != hipSuccess) sc->side = nullptr;
 		if (sc->side && (hipEventCreateWithFlags(&sc->side_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sc->side_join, hipEventDisableTiming) != hipSuccess)) {
 			(void) hipStreamDestroy(sc->side);
 			sc->side = nullptr;
