@@ -1627,6 +1627,8 @@ __device__ __forceinline__ int hit_where(const Hit& h) {
 	const int v = (h.frame == 0 ? h.slot : h.frame) | (h.extra << kExtraShift);
 	return h.frame == 0 ? v : -v;
 }
+// (measured again with 32 768 segments per launch, ms per image on the mesh scene: walk on the spot from 24 lanes on 280.3,
+// from 40 on 278.8, from 56 on 280.1, never 289.9; a ring of 192 rays 285.9)
 constexpr unsigned kRing = 128;    // parked rays per wave
 constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
 #ifndef PTX_PRIMARY_WAVES
