@@ -104,9 +104,13 @@ typedef enum PtxPrimKind { PTX_SPHERE = 0, PTX_BOX = 1, PTX_TRIANGLE = 2 } PtxPr
  * Inside a frame other than the root the usual leaf is an untransformed triangle of a loaded
  * mesh (all of a frame's go into one BVH).  A sphere, a box or a triangle with a transform of
  * its own may live there too - a Composite a caller filled with shapes and moved as a whole, a
- * face of a moved mesh part moved once more - if it lies directly below the frame's Composite
- * (levels_in == 0); below an untransformed Composite in there it would be gated by bounds it may
- * have left, which the description carries for the root only: PTX_ERR_UNSUPPORTED.
+ * face of a mesh part moved on its own - if it lies directly below the frame's Composite
+ * (levels_in == 0).  An UNtransformed Composite that holds such a leaf (a part of a loaded mesh
+ * one face of which was moved, an octant of such a part) gates the leaf with the bounds_ it had
+ * before the leaf moved (nothing rebuilds them): the hand-over lists such a Composite as a
+ * frame of its own, with its identity matrices, so that its bounds test is kept - the working
+ * flatten does (host/flatten.cpp, holds_other_leaves) - and PTX_ERR_UNSUPPORTED is what a
+ * description gets that leaves it out (levels_in != 0 on such a leaf).
  */
 typedef struct PtxPrim {
 	int32_t kind;
@@ -278,9 +282,7 @@ void ptx_trim(void);
 /*
  * Adds, for every pixel, the sum over the selected samples of trace(primary ray)
  * (framework/renderer.cpp:74-85) to d_accum (w*h*3 floats, row-major, y up, NOT cleared
- * here).  All device work goes to `stream` (one small kernel per chunk of primary samples runs in a
- * stream of the scene's own, between two events that tie it into `stream`: work queued on `stream`
- * behind the call is behind it as well).  The sums of one call are formed in doubles in a
+ * here).  All device work goes to `stream`.  The sums of one call are formed in doubles in a
  * buffer of the scene's own (allocated at the first call, grown with the image size) and added to
  * d_accum once per pixel at the end of the call.  Host waits on the stream: none while rendering
  * when no material of the scene spawns two child rays; with such materials one per chunk of

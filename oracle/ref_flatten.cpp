@@ -52,6 +52,20 @@ bool only_plain_triangles(Composite const& c) {
 	return !c.children_.empty();
 }
 
+// an untransformed Composite that holds a sphere, a box or a moved triangle (not below a transformed Composite): handed
+// over as a frame of its own, so that its bounds test is kept
+bool holds_other_leaves(Composite const& c) {
+	for (auto const& kv : c.children_) {
+		Shape const& s = *kv.second;
+		if (Composite const* sub = as_composite(s)) {
+			if (is_identity(s.world_transform_) && holds_other_leaves(*sub)) return true;
+		} else if (!dynamic_cast<Triangle const*>(&s) || !is_identity(s.world_transform_)) {
+			return true;
+		}
+	}
+	return false;
+}
+
 struct Flat {
 	std::vector<PtxFrame> frames;
 	std::vector<PtxPrim> prims;
@@ -128,7 +142,7 @@ struct Walker {
 		for (auto const& kv : c.children_) {
 			Shape const& s = *kv.second;
 			if (Composite const* sub = as_composite(s)) {
-				if (!is_identity(s.world_transform_)) {  // a transformed Composite inside a transformed one: a frame inside this frame
+				if (!is_identity(s.world_transform_) || holds_other_leaves(*sub)) {  // a transformed Composite inside a transformed one (or one that must keep its own bounds test): a frame inside this frame
 					if (!seen.emplace(&s, -(int) out.frames.size()).second) continue;
 					if (!sub->bounds_) throw std::string("Composite without bounds");
 					PtxFrame f{};

@@ -27,6 +27,22 @@ bool only_plain_triangles(Composite const& c) {
 	return !c.children().empty();
 }
 
+// true when `c` holds, at any depth below it but not below a transformed Composite, a leaf that is not an untransformed
+// triangle (a sphere, a box, a triangle a caller moved).  Such a Composite cannot be melted into the mesh around it:
+// Composite::intersect tests ITS bounds_ before it looks at the leaf (composite.cpp:77-82), and the leaf may have left
+// them (nothing rebuilds them when a leaf moves), so it is handed over as a frame of its own, with its identity transform.
+bool holds_other_leaves(Composite const& c) {
+	for (auto const& kv : c.children()) {
+		Shape const& s = *kv.second;
+		if (s.kind() == Shape::Kind::composite) {
+			if (is_identity(s.world_transform()) && holds_other_leaves(static_cast<Composite const&>(s))) return true;
+		} else if (s.kind() != Shape::Kind::triangle || !is_identity(s.world_transform())) {
+			return true;
+		}
+	}
+	return false;
+}
+
 struct Walker {
 	FlatScene& out;
 	std::unordered_map<Shape const*, int> seen;
@@ -113,7 +129,7 @@ struct Walker {
 			Shape const& s = *kv.second;
 			if (s.kind() == Shape::Kind::composite) {
 				auto const& sub = static_cast<Composite const&>(s);
-				if (!is_identity(sub.world_transform())) {  // a transformed Composite inside a transformed one: a frame inside this frame
+				if (!is_identity(sub.world_transform()) || holds_other_leaves(sub)) {  // a transformed Composite inside a transformed one (or one that must keep its own bounds test): a frame inside this frame
 					if (!seen.emplace(&s, -(int) out.frames.size()).second) continue;  // (listed at its first encounter, like a leaf)
 					out.frames.push_back(frame_of(sub, frame, levels));
 					walk_mesh(sub, (int) out.frames.size() - 1, 0, path + sub.get_name() + "/", depth + 1);

@@ -206,10 +206,6 @@ struct PtxScene {
 	bool int_pow = true;     // every specular exponent is a whole number in [1, kIntPowMax] (or 0 = no specular term)
 	int profiling = 0;       // 0 off, 1 events around every launch, 2 events + the counting twins of the traversal kernels
 	std::vector<hipEvent_t> events;      // reused from call to call
-	// a stream of the scene's own, and the two events that tie it to the caller's: the order of the next depth's segments
-	// (k_order) is made there while the shadow kernel of this depth runs
-	hipStream_t side = nullptr;
-	hipEvent_t side_fork = nullptr, side_join = nullptr;
 	std::vector<unsigned> event_tag;     // launch k: kernel kind and depth ...
 	std::vector<unsigned> event_begin;   // ... and the event that marks its begin (its end: the event after that)
 	int n_prims = 0, n_frames = 0, n_nodes = 0, max_depth = 0, grid = 0;
@@ -870,9 +866,6 @@ void ptx_scene_destroy(PtxScene* scene) {
 	if (!scene) return;
 	(void) hipSetDevice(scene->device);
 	for (hipEvent_t e : scene->events) (void) hipEventDestroy(e);
-	if (scene->side_fork) (void) hipEventDestroy(scene->side_fork);
-	if (scene->side_join) (void) hipEventDestroy(scene->side_join);
-	if (scene->side) (void) hipStreamDestroy(scene->side);
 	if (scene->sums) (void) hipFree(scene->sums);
 	if (scene->undo) (void) hipFree(scene->undo);
 	if (scene->host_word) (void) hipHostFree(scene->host_word);
@@ -974,19 +967,6 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	auto shadow_count_of = [&](unsigned depth) { return M.counts + (size_t) (kMaxBounces + 2 + depth) * M.max_seg; };
 	auto hit_count_of = [&](unsigned depth) { return M.counts + (size_t) (2 * (kMaxBounces + 2) + depth) * M.max_seg; };
 	unsigned* const order = M.counts + (size_t) 3 * (kMaxBounces + 2) * M.max_seg;
-	// the stream in which k_order runs beside the shadow kernel (not where the library may create nothing)
-	if (may_create_events && !sc->side) {
-		// (the highest priority there is: its one workgroup competes with the shadow kernel's thousands for a compute unit)
-		int least = 0, greatest = 0;
-		if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
-		if (hipStreamCreateWithPriority(&sc->side, hipStreamNonBlocking, greatest) != hipSuccess) sc->side = nullptr;
-		if (sc->side && (hipEventCreateWithFlags(&sc->side_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sc->side_join, hipEventDisableTiming) != hipSuccess)) {
-			(void) hipStreamDestroy(sc->side);
-			sc->side = nullptr;
-		}
-	}
-	const bool side_ok = may_create_events && sc->side != nullptr;
-	bool side_order_made = false;  // the list of this chunk is being made in the side stream
 	// one depth of the ray tree: the fused kernel, or closest hit -> shading -> shadow rays
 	const bool ip = sc->int_pow;
 	// the general variant of the traversal kernels: frame-0 leaves under a BVH of their own, or a split root
@@ -1036,7 +1016,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 	unsigned nqueues = 0, n_seg = 0, seg_cap = 0, take = 0, take0 = 0;
 	bool two_queues = false;  // on the straight way through a chunk (below)
 	uint64_t capd = 0, chunk = 0;
-	dim3 grid(1), walk_grid(1);  // a grid is n_seg waves: in workgroups of kBlock (shading) or kWalkBlock (the kernels that walk)
+	dim3 grid(1), walk_grid(1);  // a grid is n_seg waves: in workgroups of kShadeBlock (shading) or kWalkBlock (the kernels that walk)
 	auto queue_at = [&](unsigned index) {  // queue `index` of the block: capd slots of 48 bytes, as three planes
 		RayQueue q;
 		q.a = M.qmem + (uint64_t) index * capd * 3;
@@ -1066,7 +1046,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		// that keep doubling leave a remainder then.
 		take0 = two_queues && can_remain ? std::max(64u, (take / 2) & ~63u) : take;
 		chunk = (uint64_t) take0 * n_seg;  // primary samples per launch (at most 2^30)
-		grid = dim3(n_seg / (kBlock / 64));
+		grid = dim3(n_seg / (kShadeBlock / 64));
 		walk_grid = dim3(n_seg / (kWalkBlock / 64));
 		A.seg_cap = seg_cap;
 		A.n_seg = n_seg;
@@ -1117,21 +1097,19 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		}
 		A.shadow_count = shadow_count_of(d);
 		A.hit_count = hit_count_of(d);
-		// The segments of the depths > 0 fullest first, for the three kernels of each depth (hits and shadow rays follow the
-		// rays).  The list is made ONCE per chunk, from the counts of depth 1, and serves the deeper depths as well: a
-		// segment that is full at depth 1 - its pixels lie on glass - tends to stay so, and k_order costs 57 us a time
-		// (measured, ms per image on the mesh scene: no order 287, a list per depth 288, one list per chunk 280).  On the
-		// straight way through a chunk only: there every launch takes its segments from their first record on.
+		// The segments of the depths > 0 fullest first, four at a time, for the three kernels of each depth (hits and shadow
+		// rays follow the rays).  The list is made ONCE per chunk, from the counts of depth 1, and serves the deeper depths as
+		// well: a segment that is full at depth 1 - its pixels lie on glass - tends to stay so (measured, ms per image on the
+		// mesh scene with a list of single segments at 57 us a time: no order 287, a list per depth 288, one list per chunk
+		// 282; the same made in a stream of the library's own beside the shadow kernel of depth 0: 280, not kept - a render
+		// then depends on two streams and two events being scheduled against each other, and one full test run hung in a
+		// small render).  On the straight way through a chunk only: there every launch takes its segments from their first
+		// record on.
 		const bool ordering = use_order && two_queues && n_seg >= 1024;
 		A.order = nullptr;
 		if (d > 0 && ordering) {
 			if (d == 1) {
-				if (side_order_made) {  // beside the shadow kernel of depth 0
-					HIP_TRY(hipStreamWaitEvent(stream, sc->side_join, 0));
-				} else {
-					hipLaunchKernelGGL(k_order, dim3(1), dim3(kOrderBlock), 0, stream, A.in_count, n_seg, seg_cap, A.in_first, A.in_take, order);
-				}
-				side_order_made = false;
+				hipLaunchKernelGGL(k_order, dim3(1), dim3(kOrderBlock), 0, stream, A.in_count, n_seg, seg_cap, A.in_first, A.in_take, order);
 				launches += 1;
 			}
 			A.order = order;
@@ -1158,19 +1136,11 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 			auto kern = d == 0 ? pick(std::true_type{}) : pick(std::false_type{});
 			A.stage_children = sc->branching ? 128u : 64u;
 			A.stage_lights = (unsigned) std::min(std::max(sc->dev.n_lights, 0), kStageLights);
-			const size_t stage_bytes = (size_t) (kBlock / 64) * shade_stage_f4(A.stage_children, A.stage_lights) * sizeof(float4);
-			hipLaunchKernelGGL(kern, grid, dim3(kBlock), stage_bytes, stream, A);
+			const size_t stage_bytes = (size_t) (kShadeBlock / 64) * shade_stage_f4(A.stage_children, A.stage_lights) * sizeof(float4);
+			hipLaunchKernelGGL(kern, grid, dim3(kShadeBlock), stage_bytes, stream, A);
 			PTX_TL(1, d);
 		}
 		HIP_TRY(tick(1, d, false));
-		// the list for depth 1 and deeper, made in the scene's own stream beside the shadow kernel of depth 0
-		if (ordering && side_ok && d == 0 && max_depth > 0 && sc->dev.n_lights > 0) {
-			HIP_TRY(hipEventRecord(sc->side_fork, stream));
-			HIP_TRY(hipStreamWaitEvent(sc->side, sc->side_fork, 0));
-			hipLaunchKernelGGL(k_order, dim3(1), dim3(kOrderBlock), 0, sc->side, count_of(1), n_seg, seg_cap, 0u, take, order);
-			HIP_TRY(hipEventRecord(sc->side_join, sc->side));
-			side_order_made = true;
-		}
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
 			auto kern = count_tests ? (rb ? k_shadow<true, TestCount> : k_shadow<false, TestCount>) : (rb ? k_shadow<true, NoCount> : k_shadow<false, NoCount>);

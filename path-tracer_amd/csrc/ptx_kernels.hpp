@@ -22,6 +22,12 @@ constexpr int kBlock = 256;  // 4 wave64 per workgroup
 #define PTX_WALK_BLOCK 64
 #endif
 constexpr int kWalkBlock = PTX_WALK_BLOCK;
+#ifndef PTX_SHADE_BLOCK
+#define PTX_SHADE_BLOCK 256
+#endif
+// workgroup of the shading kernel: its waves share the LDS copies of the scene's small tables (measured, ms per image on
+// the mesh scene, primary / deeper depths: 256 threads 30.0 / 76.1, 128 threads 33.7 / 76.7, 64 threads 38.9 / 80.2)
+constexpr int kShadeBlock = PTX_SHADE_BLOCK;
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 2  // waves per SIMD the bounce kernel's register budget is sized for
 #endif
@@ -1431,7 +1437,7 @@ __device__ __forceinline__ unsigned wave_id() { return __builtin_amdgcn_readfirs
 // on glass or they do not - and a grid ends when its last wave ends: taken in the order of their numbers, a full
 // segment that starts late keeps the chip waiting, nearly empty, for one wave.  k_order lists them fullest first.
 __device__ __forceinline__ unsigned segment_of(const unsigned* order, unsigned w) {
-	return order ? __builtin_amdgcn_readfirstlane(order[w]) : w;
+	return order ? __builtin_amdgcn_readfirstlane(order[w >> 2]) * 4 + (w & 3u) : w;  // (the list holds runs of four segments)
 }
 #ifdef PTX_TIMELINE
 // A build for one question - when do the waves of a launch start and end, and where? - in which every wave of the queue
@@ -1829,12 +1835,12 @@ __device__ __forceinline__ void fill_shade_lds(ShadeLds<LT>& lds, const DevScene
 	float4* const dst[6] = {reinterpret_cast<float4*>(lds.prim),  reinterpret_cast<float4*>(lds.shade), reinterpret_cast<float4*>(lds.xf),
 	                        reinterpret_cast<float4*>(lds.fwinv), reinterpret_cast<float4*>(lds.fw),    lds.mats};
 	const int total = np[0] + np[1] + np[2] + np[3] + np[4] + np[5];
-	for (int p0 = 0; p0 < total; p0 += 2 * kBlock) {
+	for (int p0 = 0; p0 < total; p0 += 2 * kShadeBlock) {
 		float4 v[2];
 		float4* to[2] = {nullptr, nullptr};
 #pragma unroll
 		for (int r = 0; r < 2; ++r) {
-			int p = p0 + r * kBlock + (int) threadIdx.x;
+			int p = p0 + r * kShadeBlock + (int) threadIdx.x;
 			v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
 			if (p < total) {
 				int t = 0;
@@ -1856,7 +1862,7 @@ template <bool PRIMARY, bool INTPOW, bool LT>
 #ifndef PTX_SHADE_GENERAL_WAVES
 #define PTX_SHADE_GENERAL_WAVES 3
 #endif
-__global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (INTPOW ? 3 : PTX_SHADE_GENERAL_WAVES)) void k_shade(BounceArgs A_) {
+__global__ __launch_bounds__(kShadeBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (INTPOW ? 3 : PTX_SHADE_GENERAL_WAVES)) void k_shade(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
 	__shared__ ShadeLds<LT> lds;
@@ -1876,8 +1882,8 @@ __global__ __launch_bounds__(kBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES : (I
 		stage.shadow_b = stage.shadow_a + 64 * A.stage_lights;
 	}
 	const unsigned lane = lane_id();
-	const unsigned wave = segment_of(A.order, wave_id());
-	const WaveTimer timer(wave_id(), wave);
+	const unsigned wave = segment_of(A.order, wave_id<kShadeBlock>());
+	const WaveTimer timer(wave_id<kShadeBlock>(), wave);
 	const unsigned n = min(A.hit_count[wave], A.seg_cap);
 	const unsigned steps = (n + 63) >> 6;
 	const size_t seg_base = (size_t) wave * A.seg_cap;
@@ -2151,45 +2157,47 @@ __global__ __launch_bounds__(kWalkBlock, PTX_SHADOW_WAVES) void k_shadow(BounceA
 #undef A
 }
 
-// order[] = the segments of one depth sorted by the number of 64-record steps a launch takes of them, most first: a
-// counting sort in ONE workgroup (n_seg is some ten thousand).  Every thread reads all its segments' counts at once,
-// every wave counts into bins of its own in LDS and the places of a bin go to the waves in turn.  It takes 57 us for
-// 32 768 segments - the lanes of a wave mostly hold the same few step counts and queue for the same words of LDS, on the
-// one compute unit the workgroup runs on -, so it is made once per chunk of primary samples, in a stream of the scene's
-// own beside the shadow kernel of depth 0 (render_accumulate).  Segments with equal step counts come in any order: the
-// order decides when a segment is worked on, never what is computed.
+// order[] = the runs of four segments (4 q .. 4 q + 3) of one depth sorted by the number of 64-record steps a launch
+// takes of them, most first: a counting sort in ONE workgroup, a launch of its own between two others.  Every thread reads
+// all its runs' counts at once, every wave counts into bins of its own in LDS and the places of a bin go to the waves in
+// turn.  Runs of four because the kernel's time goes with the number of items (the lanes of a wave mostly hold the same
+// few step counts and queue for the same words of LDS, on the one compute unit the workgroup runs on: 57 us for 32 768
+// single segments) and the order need not be finer: neighbouring segments hold neighbouring pixels' rays.  Runs with
+// equal step counts come in any order: the order decides when a segment is worked on, never what is computed.
 //   (tried instead: the waves of the shading kernel, which know the counts first, count their segments into the bins
 //   with one global atomic each, and a kernel of many workgroups places them: the 32 768 atomics of a launch fall on a
 //   handful of cache lines - most segments hold about the same - and cost the shading kernel 4 ms per depth.)
 constexpr int kOrderBlock = 1024;
 constexpr int kOrderBins = 128;
-constexpr int kOrderPer = (int) (kMaxSeg / kOrderBlock) > 0 ? (int) (kMaxSeg / kOrderBlock) : 1;  // segments per thread
-static_assert(kMaxSeg % kOrderBlock == 0 || kMaxSeg < (unsigned) kOrderBlock, "k_order: segments per thread");
+constexpr int kOrderPer = (int) (kMaxSeg / 4 / kOrderBlock) > 0 ? (int) (kMaxSeg / 4 / kOrderBlock) : 1;  // runs per thread
+static_assert(kMaxSeg / 4 <= (unsigned) (kOrderPer * kOrderBlock), "k_order: runs per thread");
 __global__ __launch_bounds__(kOrderBlock) void k_order(const unsigned* __restrict__ count, unsigned n_seg, unsigned seg_cap, unsigned first, unsigned take,
                                                        unsigned* __restrict__ order) {
 	constexpr int kWaves = kOrderBlock / 64;
-	__shared__ unsigned bin[kWaves][kOrderBins];  // per wave: segments per bin, then the first place of the wave's share of the bin
+	__shared__ unsigned bin[kWaves][kOrderBins];  // per wave: runs per bin, then the first place of the wave's share of the bin
 	__shared__ unsigned total[kOrderBins];
 	const unsigned t = threadIdx.x, w = t >> 6, lane = t & 63u;
-	const unsigned max_steps = (seg_cap + 63) / 64;
-	unsigned raw[kOrderPer];
+	const unsigned n_runs = n_seg / 4;  // (n_seg is a multiple of four)
+	const unsigned max_steps = 4 * ((seg_cap + 63) / 64);
+	uint4 raw[kOrderPer];
 #pragma unroll
 	for (int k = 0; k < kOrderPer; ++k) {
-		const unsigned s = (unsigned) k * kOrderBlock + t;
-		raw[k] = count[s < n_seg ? s : 0u];
+		const unsigned q = (unsigned) k * kOrderBlock + t;
+		raw[k] = reinterpret_cast<const uint4*>(count)[q < n_runs ? q : 0u];
 	}
 	for (unsigned i = t; i < (unsigned) (kWaves * kOrderBins); i += kOrderBlock) (&bin[0][0])[i] = 0;
 	__syncthreads();
 	unsigned key[kOrderPer];
 #pragma unroll
 	for (int k = 0; k < kOrderPer; ++k) {
-		const unsigned steps = (taken(raw[k], seg_cap, first, take) + 63) >> 6;
+		const unsigned steps = ((taken(raw[k].x, seg_cap, first, take) + 63) >> 6) + ((taken(raw[k].y, seg_cap, first, take) + 63) >> 6) +
+		                       ((taken(raw[k].z, seg_cap, first, take) + 63) >> 6) + ((taken(raw[k].w, seg_cap, first, take) + 63) >> 6);
 		const unsigned q = max_steps < (unsigned) kOrderBins ? steps : (unsigned) ((unsigned long long) steps * (kOrderBins - 1) / max_steps);
 		key[k] = (unsigned) (kOrderBins - 1) - min(q, (unsigned) (kOrderBins - 1));  // most steps first
-		if ((unsigned) k * kOrderBlock + t < n_seg) atomicAdd(&bin[w][key[k]], 1u);
+		if ((unsigned) k * kOrderBlock + t < n_runs) atomicAdd(&bin[w][key[k]], 1u);
 	}
 	__syncthreads();
-	if (t < (unsigned) kOrderBins) {  // a bin's segments over all waves ...
+	if (t < (unsigned) kOrderBins) {  // a bin's runs over all waves ...
 		unsigned sum = 0;
 		for (int v = 0; v < kWaves; ++v) sum += bin[v][t];
 		total[t] = sum;
@@ -2227,8 +2235,8 @@ __global__ __launch_bounds__(kOrderBlock) void k_order(const unsigned* __restric
 	__syncthreads();
 #pragma unroll
 	for (int k = 0; k < kOrderPer; ++k) {
-		const unsigned s = (unsigned) k * kOrderBlock + t;
-		if (s < n_seg) order[atomicAdd(&bin[w][key[k]], 1u)] = s;
+		const unsigned q = (unsigned) k * kOrderBlock + t;
+		if (q < n_runs) order[atomicAdd(&bin[w][key[k]], 1u)] = q;
 	}
 }
 

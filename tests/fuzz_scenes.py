@@ -147,6 +147,11 @@ def scene_moves(seed):
     if mesh == "sword" and any(o[0].endswith("Blade_Cube") for o in ops):
         ops.append(("sword/Blade_Cube/face60", "translate", 0.2, 0.1, 0.0))
         ops.append(("sword/Blade_Cube/face55", "rotate", 0.0, 0.3, 0.2))
+    if mesh == "sword":     # a face of a part that stays where it is (the part keeps its bounds: the face is cut off where it leaves them)
+        first_face = {"Grip_Cube.004": 0, "Guard_Cube.002": 12, "Pommel_Cube.003": 32, "Blade_Cube": 52}
+        still = [q for q in parts if not any(o[0] == f"sword/{q}" for o in ops)]
+        q = still[int(rng.integers(0, len(still)))]
+        ops.append((f"sword/{q}/face{first_face[q] + int(rng.integers(0, 12))}", "translate", *(float(v) for v in rng.uniform(-0.3, 0.3, 3))))
     group, group_ops = None, []
     if seed % 8 in (2, 4):
         kids = []

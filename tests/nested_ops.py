@@ -34,6 +34,11 @@ GROUP_OPS = [
     ("grp", "scale", 1.2, 0.9, 1.1),
     ("sword/Blade_Cube/face60", "translate", 0.3, 0.0, 0.0),
     ("sword/Blade_Cube/face61", "rotate", 0.0, 0.0, 0.3),
+    # faces of parts that were NOT moved: the part (an untransformed Composite inside the moved mesh) keeps the bounds it
+    # had, and a face that leaves them is cut off there; and a face inside an octant of a part with more than 64 faces
+    ("sword/Grip_Cube.004/face3", "translate", 0.0, 0.0, 0.25),
+    ("sword/Pommel_Cube.003/face38", "translate", 0.0, 0.15, 0.3),
+    ("superhot/right_leg_Superhot_Enemy_Stl.003/0/face249", "translate", 0.1, 0.0, 0.1),
 ]
 
 

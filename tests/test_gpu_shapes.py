@@ -499,7 +499,10 @@ def test_shapes_grouped_and_moved_together(pt, port):
     """Leaves that are not plain triangles inside transformed Composites: on top of the moved mesh parts of
     test_moved_parts_of_loaded_meshes, a Composite of the caller's own with two spheres and two boxes is added to the
     root and moved as a whole (translate, rotate, uneven scale), its members are moved once more inside it, and two
-    faces of the sword's blade - itself a moved part of a moved mesh - are moved on their own (tests/nested_ops.py).
+    faces of the sword's blade - itself a moved part of a moved mesh - are moved on their own, and so are faces of
+    parts that were not moved, one of them inside an octant of a part with more than 64 faces (tests/nested_ops.py;
+    an untransformed Composite keeps the bounds it had, and a face that leaves them is cut off there: such a
+    Composite is handed over as a frame of its own).
     Every such leaf is reached through the chain of frames above it and its own inverse, and reports position,
     normal and ray direction as Sphere / Box / Triangle::intersect and the Composites above would: hit identity exact,
     distance, position, normal, ray direction bit-identical to the oracle (pinned to the real reference on this scene
@@ -514,9 +517,10 @@ def test_shapes_grouped_and_moved_together(pt, port):
     assert hs.prim_names() == port.leaf_names(s)
     d = hs.desc.contents
     inside = [i for i in range(d.n_prims) if d.prims[i].frame > 0 and (d.prims[i].kind != 2 or any(d.prims[i].world[k] != (1.0 if k % 5 == 0 else 0.0) for k in range(16)))]
-    assert len(inside) == 6 and {d.prims[i].kind for i in inside} == {0, 1, 2}
+    assert len(inside) == 9 and {d.prims[i].kind for i in inside} == {0, 1, 2}
+    assert all(d.prims[i].levels_in == 0 for i in inside)      # (an untransformed Composite that holds such a leaf is handed over as a frame of its own)
     ds = pt.DeviceScene(hs, 0, 1 << 28)
-    o1, d1 = port.primary_rays(s, 240, 160, 1)
+    o1, d1 = port.primary_rays(s, 960, 640, 1)      # (dense: the single moved faces are small)
     o2, d2 = random_rays(60000, 11, lo=(-8, -1, -20), hi=(8, 10, 4))
     o, dd = np.concatenate([o1, o2]), np.concatenate([d1, d2])
     a, b = ds.intersect(o, dd), port.intersect(s, o, dd)
@@ -526,6 +530,8 @@ def test_shapes_grouped_and_moved_together(pt, port):
     for leaf in ("grp/gs1", "grp/gs2", "grp/gb1", "grp/gb2"):
         assert (paths == leaf).sum() > 30, leaf
     assert np.isin(paths, ["sword/Blade_Cube/face60", "sword/Blade_Cube/face61"]).sum() > 20
+    for leaf in ("sword/Grip_Cube.004/face3", "sword/Pommel_Cube.003/face38", "superhot/right_leg_Superhot_Enemy_Stl.003/0/face249"):
+        assert (paths == leaf).sum() >= 10, leaf
     for k in ("t", "pos", "normal", "raydir"):
         assert beq(a[k][m], b[k][m]), k
     ref = port.render(s, 160, 100, 2, 4)
