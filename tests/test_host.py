@@ -98,6 +98,47 @@ def test_octree_statistics_of_the_mesh_scenes(pt, scenes):
     assert sum(1 for n in names if n.startswith("superhot/")) == 999
 
 
+def test_moved_parts_become_frames_inside_frames(pt):
+    """What a C++ caller does after load_scene (tests/nested_ops.py: parts of the loaded meshes, a Composite of spheres
+    and boxes of the caller's own, single faces moved through find_child, framework/composite.cpp:112-114, :168-181):
+    every Composite that is transformed, or holds a leaf that is, is handed over as a frame of its own whose parent
+    comes earlier in the list; leaves of any kind may lie in a frame; a part that was not moved but holds a moved face
+    is a frame with identity matrices."""
+    from nested_ops import apply_group
+    hs = pt.HostScene(pt.SDF_DIR + "/nested.sdf")
+    assert hs.desc.contents.n_frames == 3
+    n_before = hs.desc.contents.n_prims
+    apply_group(hs, None)
+    d = hs.desc.contents
+    names = hs.prim_paths()
+    assert d.n_prims == n_before + 4 and len(set(names)) == d.n_prims
+    assert d.n_frames > 3 and d.frames[0].parent == -1
+    depth = [0] * d.n_frames
+    for f in range(1, d.n_frames):
+        F = d.frames[f]
+        assert 0 <= F.parent < f
+        depth[f] = depth[F.parent] + 1
+        assert F.levels_up == (1 if F.parent == 0 else 0)   # the root's bounds test is counted at the root's children only
+    assert 2 <= max(depth) <= 8
+    frame_of = {names[i]: d.prims[i].frame for i in range(d.n_prims)}
+    kind_of = {names[i]: d.prims[i].kind for i in range(d.n_prims)}
+    grp = frame_of["grp/gs1"]
+    assert grp > 0 and d.frames[grp].parent == 0 and all(frame_of["grp/" + n] == grp for n in ("gs2", "gb1", "gb2"))
+    assert sorted(kind_of["grp/" + n] for n in ("gs1", "gs2", "gb1", "gb2")) == [0, 0, 1, 1]
+    blade = frame_of["sword/Blade_Cube/face60"]
+    sword = d.frames[blade].parent
+    assert sword > 0 and d.frames[sword].parent == 0
+    # a part nobody moved that holds a moved face: a frame of its own with identity matrices
+    grip = frame_of["sword/Grip_Cube.004/face3"]
+    ident = [1.0 if r == c else 0.0 for c in range(4) for r in range(4)]
+    assert grip not in (0, sword, blade) and d.frames[grip].parent == sword
+    assert list(d.frames[grip].world) == ident and list(d.frames[grip].world_inv) == ident
+    assert list(d.frames[blade].world) != ident
+    # the moved face itself carries its own matrices, its neighbours in the same part do not
+    i, j = names.index("sword/Grip_Cube.004/face3"), names.index("sword/Grip_Cube.004/face0")
+    assert list(d.prims[i].world)[12:15] == [0.0, 0.0, 0.25] and list(d.prims[j].world) == ident
+
+
 def test_levels_and_frames(pt, scenes):
     d = scenes.host_scene("example").desc.contents
     prims = [d.prims[i] for i in range(d.n_prims)]
