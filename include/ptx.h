@@ -36,7 +36,7 @@ extern "C" {
 typedef enum PtxStatus {
 	PTX_OK = 0,
 	PTX_ERR_INVALID = 1,     /* bad argument / malformed scene description            */
-	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (a sphere, box or moved triangle below an untransformed Composite inside a transformed one; transformed Composites more than 8 deep, or inside one another under a split root) */
+	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (a sphere, box or moved triangle below an untransformed Composite inside a transformed one; transformed Composites more than 8 deep) */
 	PTX_ERR_DEVICE = 3,      /* HIP call failed, or no gfx950 device                  */
 	PTX_ERR_OVERFLOW = 4,    /* a ray queue filled up: result discarded, see message  */
 	PTX_ERR_NOMEM = 5
@@ -140,8 +140,10 @@ typedef struct PtxPrim {
  *                the first: the octant the entry sits in and the leaf (index into prims) or mesh
  *                (frame index) it names.  A child of several octants has several occurrences.
  * With n_guards == 0 (a root of at most 64 children: every scene shipped with the reference)
- * both lists are ignored.  With guards, every frame-0 leaf and every frame needs at least one
- * occurrence, and levels_in of frame-0 leaves / levels_up of frames are taken from the guards.
+ * both lists are ignored.  With guards, every frame-0 leaf and every frame that lies directly in
+ * the root (parent == 0) needs at least one occurrence, and levels_in of frame-0 leaves / levels_up
+ * of those frames are taken from the guards.  A frame inside another frame has no occurrence of its
+ * own: rays reach it through those of the frame at the top of its chain.
  */
 typedef struct PtxGuard {
 	float bounds_min[3], bounds_max[3];
@@ -152,7 +154,7 @@ typedef struct PtxGuard {
 typedef struct PtxOccurrence {
 	int32_t guard; /* index into guards; -1: directly under the root */
 	int32_t prim;  /* a leaf: its index in prims; -1 for a mesh */
-	int32_t frame; /* a mesh: its frame (>= 1); 0 for a leaf */
+	int32_t frame; /* a mesh: its frame (>= 1, one with parent == 0); 0 for a leaf */
 	int32_t reserved;
 } PtxOccurrence;
 

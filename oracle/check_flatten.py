@@ -113,16 +113,16 @@ def main():
     # the generated scenes of the parity tests (tests/fuzz_scenes.py): random and quarter-turn transforms, split roots, two meshes
     import tempfile
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
-    from fuzz_scenes import apply_moves, write_scene
+    from fuzz_scenes import apply_moves, mesh_prefix, write_scene
     tmp = tempfile.mkdtemp()
     bad = []
     n_gen = int(os.environ.get("PTX_FUZZ_SEEDS", "18"))
     for seed in range(n_gen):
         path, obj_dir = write_scene(seed, tmp, SDF_DIR)
         rs = ref.load(path)
-        apply_moves(ref, rs, seed)
-        a, an = ref_parts(ref, rs)
         hs = pt.HostScene(path, obj_dir)
+        apply_moves(ref, rs, seed, mesh_prefix(hs, None, seed))
+        a, an = ref_parts(ref, rs)
         apply_moves(hs, None, seed)
         b, bn = mirror_parts(pt, path, hs)
         if not (all(a[k] == b[k] for k in PARTS) and an == bn):

@@ -352,7 +352,6 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		if (depth > kMaxNest) return fail(PTX_ERR_UNSUPPORTED, "frame " + std::to_string(f) + ": transformed Composites nested deeper than " + std::to_string(kMaxNest));
 		nested = nested || p > 0;
 	}
-	if (nested && D->n_guards > 0) return fail(PTX_ERR_UNSUPPORTED, "a split root (more than 64 children) together with transformed Composites inside transformed Composites");
 	// ---- octants of a split root
 	const bool guarded = D->n_guards > 0;
 	if (D->n_guards < 0 || D->n_occurrences < 0 || (guarded && (!D->guards || !D->occurrences)))
@@ -369,9 +368,9 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		for (int k = 0; k < D->n_occurrences; ++k) {
 			const PtxOccurrence& O = D->occurrences[k];
 			const bool leaf = O.prim >= 0 && O.prim < D->n_prims && O.frame == 0 && D->prims[O.prim].frame == 0;
-			const bool mesh = O.prim == -1 && O.frame >= 1 && O.frame < D->n_frames;
+			const bool mesh = O.prim == -1 && O.frame >= 1 && O.frame < D->n_frames && D->frames[O.frame].parent == 0;
 			if (O.guard < -1 || O.guard >= D->n_guards || !(leaf || mesh))
-				return fail(PTX_ERR_INVALID, "occurrence " + std::to_string(k) + ": names no octant, or neither a frame-0 leaf nor a mesh frame");
+				return fail(PTX_ERR_INVALID, "occurrence " + std::to_string(k) + ": names no octant, or neither a frame-0 leaf nor a frame that lies directly in the root");
 		}
 	}
 	// ---- every index and count the set-up below and the kernels rely on, before anything touches a device
@@ -437,6 +436,13 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		frame_id_lo[f] = std::min(frame_id_lo[f], i);
 		frame_id_hi[f] = std::max(frame_id_hi[f], i);
 	}
+	// (a frame that holds frames: the prim ids of everything below it, one run, as the depth-first listing gives them)
+	for (int f = D->n_frames - 1; f >= 1; --f) {
+		const int p = D->frames[f].parent;
+		if (p <= 0 || frame_id_hi[f] < 0) continue;
+		frame_id_lo[p] = std::min(frame_id_lo[p], frame_id_lo[f]);
+		frame_id_hi[p] = std::max(frame_id_hi[p], frame_id_hi[f]);
+	}
 	if (guarded) {
 		int64_t key = 0;
 		for (int k = 0; k < D->n_occurrences; ++k) {
@@ -492,7 +498,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 					n = normalize(xform_dir(F.world, n));
 					// (split root: once for the root here, once more per octant level above the occurrence
 					// of the mesh a ray came through when the hit is shaded)
-					for (int k = 0; k < (guarded ? 1 : F.levels_up); ++k) n = up_one_level(n);
+					for (int k = 0; k < (guarded && F.parent == 0 ? 1 : F.levels_up); ++k) n = up_one_level(n);
 				}
 			} else if (P.kind == PTX_TRIANGLE) {
 				n = xform_dir(P.world, n);
@@ -595,17 +601,22 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 		for (int k = 0; k < 3; ++k) G.tinv[k] = F.world_inv[12 + k];
 		std::memcpy(G.bmin, F.bounds_min, sizeof G.bmin);
 		std::memcpy(G.bmax, F.bounds_max, sizeof G.bmax);
-		G.levels_up = F.levels_up;
+		G.levels_up = guarded && F.parent == 0 ? 1 : F.levels_up;  // (split root: the octant levels come with the occurrence a ray came through)
 		G.parent = F.parent;
 		G.plain = pure_translation(F.world) && pure_translation(F.world_inv);
 		auto const& ids = frame_tris[f];
 		G.has_prims = !ids.empty();
-		if (ids.empty()) continue;
 		if (guarded) {
-			if (mesh_occ[f].empty()) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": a mesh of a split root without an occurrence");
-			frame_occ[f] = make_int4((int) occ.size(), (int) mesh_occ[f].size(), frame_id_lo[f], 0);
-			occ.insert(occ.end(), mesh_occ[f].begin(), mesh_occ[f].end());
+			// the entries of the root's child this frame is, or lies in (frames come after the frame they lie in)
+			if (F.parent > 0) {
+				frame_occ[f] = frame_occ[F.parent];
+			} else if (frame_id_hi[f] >= 0) {
+				if (mesh_occ[f].empty()) return fail(PTX_ERR_INVALID, "frame " + std::to_string(f) + ": a mesh of a split root without an occurrence");
+				frame_occ[f] = make_int4((int) occ.size(), (int) mesh_occ[f].size(), frame_id_lo[f], 0);
+				occ.insert(occ.end(), mesh_occ[f].begin(), mesh_occ[f].end());
+			}
 		}
+		if (ids.empty()) continue;
 		std::vector<ptx::Aabb> boxes(ids.size());
 		for (size_t k = 0; k < ids.size(); ++k) {
 			const float* p = D->prims[ids[k]].p;
@@ -765,6 +776,10 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 	S.nan_id = -1;
 	S.nan_frame = S.nan_slot = S.nan_extra = 0;
 	S.nan_t = 0.0f;
+	auto octant_levels_above = [&](int frame) {  // split root: of the first entry of the root's child `frame` is, or lies in
+		while (D->frames[frame].parent > 0) frame = D->frames[frame].parent;
+		return mesh_occ[frame].empty() || mesh_occ[frame].front().x < 0 ? 0 : D->guards[mesh_occ[frame].front().x].levels - 1;
+	};
 	for (int i = 0; i < D->n_prims && S.nan_id < 0; ++i) {
 		const PtxPrim& P = D->prims[i];
 		if (P.kind == PTX_SPHERE) continue;
@@ -773,7 +788,8 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 				if (root_prims[k].id == i) {
 					S.nan_id = i;
 					S.nan_slot = (int32_t) k;
-					if (guarded) S.nan_extra = prim_occ[i].front().x >= 0 ? D->guards[prim_occ[i].front().x].levels - 1 : 0;
+					if (guarded && P.frame == 0) S.nan_extra = prim_occ[i].front().x >= 0 ? D->guards[prim_occ[i].front().x].levels - 1 : 0;
+					if (guarded && P.frame > 0) S.nan_extra = octant_levels_above(P.frame);
 				}
 		} else if (frames[P.frame].has_prims) {
 			const DevFrame& G = frames[P.frame];
@@ -785,7 +801,7 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 					S.nan_id = i;
 					S.nan_frame = P.frame;
 					S.nan_slot = (int32_t) k;
-					if (guarded) S.nan_extra = mesh_occ[P.frame].front().x >= 0 ? D->guards[mesh_occ[P.frame].front().x].levels - 1 : 0;
+					if (guarded) S.nan_extra = octant_levels_above(P.frame);
 				}
 			}
 		}

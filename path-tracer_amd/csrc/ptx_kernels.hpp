@@ -729,20 +729,27 @@ __device__ __forceinline__ void closest_frames(const DevScene& S, f3 o, f3 d, co
 			const DevFrame F = kload(S.frames_k + f);
 			const int2 leaves = S.frame_leaves[f];
 			if (!F.has_prims && !leaves.y) continue;
+			int bias = 0, extra = 0;
+			if (S.n_guards) {  // split root: only through an octant the ray enters, on the way to the root's child the chain starts at
+				const int4 fo = S.frame_occ[f];
+				int key;
+				if (!first_reachable(S, fo.x, fo.y, o, d, pre, key, extra, tc)) continue;
+				bias = key - fo.z;
+			}
 			f3 lo, ld;
 			if (!enter_nested(S, f, o, d, lo, ld, tc)) continue;
 			for (int j = leaves.x; j < leaves.x + leaves.y; ++j) {
 				float t;
 				int id;
-				if (frame_leaf_t(S, j, lo, ld, t, id, tc) && (t < best.t || (t == best.t && id < best.id))) {
+				if (frame_leaf_t(S, j, lo, ld, t, id, tc) && (t < best.t || (t == best.t && id + bias < best.id))) {
 					best.t = t;
-					best.id = id;
+					best.id = id + bias;
 					best.frame = 0;  // (a leaf is named by its slot, like a leaf of the root)
 					best.slot = j;
-					best.extra = 0;
+					best.extra = extra;
 				}
 			}
-			if (F.has_prims) bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, 0, 0);
+			if (F.has_prims) bvh_walk<false>(S.nodes + F.node_base, S.tris + F.tri_base, F.bvh_root, f, lo, ld, stk, best, 0.0f, tc, bias, extra);
 		}
 		return;
 	}
@@ -833,6 +840,11 @@ __device__ __forceinline__ bool trace_any(const DevScene& S, f3 o, f3 d, float r
 		if (RB && S.nested) {  // frames inside frames: through the whole chain of frames above the mesh
 			const int2 leaves = S.frame_leaves[f];
 			if (!F.has_prims && !leaves.y) continue;
+			if (S.n_guards) {
+				const int4 fo = S.frame_occ[f];
+				int key, extra;
+				if (!first_reachable(S, fo.x, fo.y, o, d, pre, key, extra, tc)) continue;
+			}
 			f3 lo, ld;
 			if (!enter_nested(S, f, o, d, lo, ld, tc)) continue;
 			bool found = false;

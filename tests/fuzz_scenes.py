@@ -126,9 +126,8 @@ def scene_moves(seed):
     Composite -, in some scenes a face of a moved part moved once more and a Composite of the caller's own with spheres
     and boxes in it, moved as a whole and member by member.  Returns (ops, group, group_ops): ops as
     (path, 'translate' | 'rotate' | 'scale', a, b, c), group as (name, [(kind, name, numbers, material)])."""
-    n = N_SHAPES[seed % len(N_SHAPES)]
-    if seed % 2 or not (seed % 4 == 0 or seed % 8 == 2) or n > 30:
-        return None     # no mesh, left as loaded, or a root the reference splits (frames inside frames are not taken under a split root)
+    if seed % 2 or not (seed % 4 == 0 or seed % 8 == 2):
+        return None     # no mesh, or left as loaded
     rng = np.random.default_rng(5000 + seed)
     S = scene_scale(seed)
     mesh = MESHES[(seed // 2) % len(MESHES)]
@@ -171,16 +170,32 @@ def scene_moves(seed):
     return ops, group, group_ops
 
 
-def apply_moves(impl, scene, seed):
+def mesh_prefix(impl, scene, seed):
+    """Where a caller finds the mesh of scene `seed`: "" when it is a child of the root, the names of the octants above it
+    ("4/1/") when the root has more than 64 children and was split (find_child looks at one level, composite.cpp:112-114;
+    the first octant in visiting order that holds the mesh - the others hold the same object).  impl: oracle_lib.Port
+    (scene = its handle) or a path-tracer_amd HostScene (scene = None)."""
+    mesh = MESHES[(seed // 2) % len(MESHES)]
+    for path in (impl.prim_paths() if scene is None else impl.leaf_paths(scene)):
+        names = path.split("/")[:-1]
+        if mesh in names:
+            return "".join(n + "/" for n in names[:names.index(mesh)])
+    return ""
+
+
+def apply_moves(impl, scene, seed, prefix=None):
     """scene_moves(seed) applied through oracle_lib.Port / Reference (scene = their handle) or a path-tracer_amd HostScene
-    (scene = None); returns whether the scene has any"""
+    (scene = None); returns whether the scene has any.  prefix: mesh_prefix() of the scene (looked up here when the
+    implementation can list its leaves' paths; the Reference shim cannot and needs it passed in)"""
     moves = scene_moves(seed)
     if moves is None:
         return False
     ops, group, group_ops = moves
     args = () if scene is None else (scene,)
+    if prefix is None:
+        prefix = mesh_prefix(impl, scene, seed)
     for path, op, a, b, c in ops:
-        impl.transform_child(*args, path, op, a, b, c)
+        impl.transform_child(*args, prefix + path, op, a, b, c)
     if group:
         impl.add_group(*args, *group)
     for path, op, a, b, c in group_ops:

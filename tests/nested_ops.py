@@ -50,3 +50,35 @@ def apply_group(impl, scene):
     else:
         impl.add_group(scene, *GROUP)
     apply_ops(impl, scene, GROUP_OPS)
+
+
+# The same kinds of moves on split_root.sdf, whose root has more than 64 children and sorts them - the mesh among them -
+# into octants: frames inside frames below a child that rays reach only through an octant they enter.  A caller finds the
+# mesh through the octants (root->find_child("4")->find_child("1")->find_child("sword"): find_child looks at one level,
+# composite.cpp:112-114); the other octants the mesh lies in hold the same object.
+SPLIT_OPS = [
+    ("4/1/sword/Blade_Cube", "rotate", 0.0, 0.0, 0.12),
+    ("4/1/sword/Blade_Cube", "translate", 0.15, 0.3, 0.0),
+    ("4/1/sword/Guard_Cube.002", "scale", 1.5, 1.0, 2.0),
+    ("4/1/sword/Grip_Cube.004/face3", "translate", 0.0, 0.0, 0.25),
+    ("4/1/sword/Blade_Cube/face60", "rotate", 0.0, 0.0, 0.3),
+]
+SPLIT_GROUP = ("grp", [("sphere", "gs1", (0.0, 0.0, 0.0, 0.8), "g"), ("box", "gb1", (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), "a"),
+                       ("sphere", "gs2", (1.5, 0.3, 0.0, 0.5), "m"), ("box", "gb2", (1.0, -0.8, -0.4, 2.2, -0.3, 0.4), "d")])
+SPLIT_GROUP_OPS = [
+    ("grp/gs2", "translate", 0.0, 0.5, 0.2),
+    ("grp/gb1", "rotate", 0.5, 0.3, 0.0),
+    ("grp", "translate", -2.0, 1.0, -10.0),
+    ("grp", "rotate", 0.4, 0.2, 0.1),
+    ("grp", "scale", 1.2, 0.9, 1.1),
+]
+
+
+def apply_split(impl, scene):
+    """SPLIT_OPS, then the group and SPLIT_GROUP_OPS (on split_root.sdf)"""
+    apply_ops(impl, scene, SPLIT_OPS)
+    if scene is None:
+        impl.add_group(*SPLIT_GROUP)
+    else:
+        impl.add_group(scene, *SPLIT_GROUP)
+    apply_ops(impl, scene, SPLIT_GROUP_OPS)

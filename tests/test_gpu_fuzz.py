@@ -3,9 +3,10 @@
 Eighteen scenes: 3 to 130 spheres, boxes and triangles under the root (the leaf list, the BVH over
 the frame-0 leaves, roots the reference splits into octants), random and quarter-turn rotations,
 even and uneven scales, meshes with turned and unevenly scaled transforms, with and without an
-enclosing room, none to five lights, every shading case, four in fourteen scaled by 100, 10^4, 10^-2 or 10^-3; in five of them parts of
-the mesh are moved after loading (transformed Composites inside a transformed Composite), in three a Composite of the
-caller's own with spheres and boxes in it is added and moved.  The CPU oracle is checked against the
+enclosing room, none to five lights, every shading case, four in fourteen scaled by 100, 10^4, 10^-2 or 10^-3; in seven of them parts of
+the mesh are moved after loading (transformed Composites inside a transformed Composite; in two of the seven below a
+root the reference splits into octants), in four a Composite of the caller's own with spheres and boxes in it is added
+and moved.  The CPU oracle is checked against the
 real reference on these very scenes in tests/test_oracle.py
 (test_oracle_equals_reference_on_generated_scenes); here the device must give the oracle's
 answers: hit identity exact, t / position / normal / ray_direction bit-identical - on primary

@@ -540,3 +540,45 @@ def test_shapes_grouped_and_moved_together(pt, port):
         assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
     ds.close()
     port.free(s)
+
+
+def test_moved_parts_below_a_split_root(pt, port):
+    """Frames inside frames together with a split root: split_root.sdf (120 shapes and a mesh under a root that sorts them
+    into octants), then parts of the mesh and single faces of it are moved, and a Composite of the caller's own with
+    spheres and boxes is added beside the octants and moved (tests/nested_ops.py, SPLIT_OPS ...).  A ray reaches the mesh -
+    and everything inside it - only through an octant it enters (composite.cpp:75-103), the hit's normal is re-normalised
+    once more per octant level on the way up (:100), and among equal distances the child met first wins.  Hit identity
+    exact; distance, position, normal, ray direction bit-identical to the oracle (pinned to the real reference on this
+    very scene by tests/test_oracle.py); images at the usual bar."""
+    from nested_ops import apply_split
+    from oracle_lib import random_rays
+    path = pt.SDF_DIR + "/split_root.sdf"
+    hs = pt.HostScene(path)
+    apply_split(hs, None)
+    s = port.load(path)
+    apply_split(port, s)
+    assert hs.prim_names() == port.leaf_names(s)
+    d = hs.desc.contents
+    assert d.n_guards >= 8 and sorted(d.frames[f].parent for f in range(d.n_frames)) == [-1, 0, 0, 1, 1, 1]
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    o1, d1 = port.primary_rays(s, 720, 480, 1)
+    o2, d2 = random_rays(60000, 11, lo=(-12, -8, -32), hi=(12, 6, 4))
+    o, dd = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, dd), port.intersect(s, o, dd)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    paths = np.array(hs.prim_paths())[b["rank"][m]]
+    for part in ("4/1/sword/Blade_Cube/", "4/1/sword/Guard_Cube.002/", "4/1/sword/Grip_Cube.004/", "4/1/sword/Pommel_Cube.003/"):
+        assert sum(n.startswith(part) for n in paths) > 50, part
+    for leaf in ("grp/gs1", "grp/gs2", "grp/gb1", "grp/gb2"):
+        assert (paths == leaf).sum() > 30, leaf
+    for leaf in ("4/1/sword/Grip_Cube.004/face3", "4/1/sword/Blade_Cube/face60"):
+        assert (paths == leaf).sum() >= 10, leaf
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    ref = port.render(s, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    ds.close()
+    port.free(s)

@@ -131,7 +131,7 @@ def test_oracle_equals_reference_on_generated_scenes(port, tmp_path, seed):
     position, normal and ray direction on primary rays, random rays and rays with zero direction
     components, and a bit-identical small image.  Container-only (needs oracle/_ref/libref.so); it
     is what makes the oracle a pinned checker on these scenes too."""
-    from fuzz_scenes import apply_moves, rays, same_bits_or_both_nan, write_scene
+    from fuzz_scenes import apply_moves, mesh_prefix, rays, same_bits_or_both_nan, write_scene
     from oracle_lib import Reference
     if not Reference.available():
         pytest.skip("oracle/_ref/libref.so absent")
@@ -139,8 +139,9 @@ def test_oracle_equals_reference_on_generated_scenes(port, tmp_path, seed):
     from oracle_lib import SDF_DIR
     sdf, obj_dir = write_scene(seed, tmp_path, SDF_DIR)
     s, r = port.load(sdf, obj_dir), ref.load(sdf)
+    where = mesh_prefix(port, s, seed)
     apply_moves(port, s, seed)      # (some scenes: parts of the mesh moved after loading, a Composite of the caller's own)
-    apply_moves(ref, r, seed)
+    apply_moves(ref, r, seed, where)
     leaf = port.leaf_names(s)
     o1, d1 = port.primary_rays(s, 60, 40, 1)
     o2, d2 = rays(seed, 4000, 1500)
@@ -187,7 +188,7 @@ def test_oracle_equals_reference_on_hand_written_fixtures(port, tmp_path, name):
     assert np.array_equal(ia["rgb"], ib["rgb"]) and same_bits_or_both_nan(ia["color"], ib["color"])
 
 
-@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("grouped", [False, True, "split_root"])
 def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     """nested.sdf with parts of its two loaded meshes moved after load_scene (tests/nested_ops.py:
     root->find_child(..)->find_child(..)->translate / rotate / scale with the reference's own methods):
@@ -196,31 +197,34 @@ def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     and the scene hand-over written against the reference's classes equals the host mirror's byte for byte, with
     the chain of frames in it.  grouped: in addition a Composite of the caller's own with spheres and boxes in it, moved as
     a whole and member by member, and single faces of a moved mesh part moved once more (leaves that are not plain
-    triangles inside transformed Composites).  Container-only (needs oracle/_ref/libref.so)."""
+    triangles inside transformed Composites).  split_root: the same kinds of moves on split_root.sdf, where the mesh is
+    reached through the octants of a root with more than 64 children.  Container-only (needs oracle/_ref/libref.so)."""
     import importlib
     import sys
     from conftest import REPO
-    from nested_ops import apply_group, apply_ops
+    from nested_ops import apply_group, apply_ops, apply_split
     if grouped:
-        apply_ops = apply_group     # noqa: F811
+        apply_ops = apply_split if grouped == "split_root" else apply_group     # noqa: F811
     from oracle_lib import Reference, SDF_DIR, random_rays
     if not Reference.available():
         pytest.skip("oracle/_ref/libref.so absent")
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import check_flatten as cf
     ref = Reference()
-    path = os.path.join(SDF_DIR, "nested.sdf")
+    path = os.path.join(SDF_DIR, "split_root.sdf" if grouped == "split_root" else "nested.sdf")
     s, r = port.load(path), ref.load(path)
     apply_ops(port, s)
     apply_ops(ref, r)
     leaf = port.leaf_names(s)
     o1, d1 = port.primary_rays(s, 160, 100, 1)
     o2, d2 = random_rays(40000, 7, lo=(-8, -1, -20), hi=(8, 10, 4))
+    if grouped == "split_root":
+        o2, d2 = random_rays(40000, 7, lo=(-12, -8, -32), hi=(12, 6, 4))
     o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
     a, b = port.intersect(s, o, d), ref.intersect(r, o, d)
     assert np.array_equal(a["hit"], b["hit"])
     m = a["hit"]
-    assert m.sum() > 20000
+    assert m.sum() > (5000 if grouped == "split_root" else 20000)
     assert [leaf[k] for k in a["rank"][m]] == [n for n, h in zip(b["names"], m) if h]
     for k in ("t", "pos", "raydir", "normal"):
         assert np.array_equal(a[k][m].view(np.uint32), b[k][m].view(np.uint32)), k
@@ -237,5 +241,7 @@ def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     d = hs.desc.contents
     if not grouped:
         assert sorted(d.frames[f].parent for f in range(d.n_frames)) == [-1, 0, 0, 1, 1, 4, 4]
+    elif grouped == "split_root":   # (the sword with three of its parts as frames inside it, and the group; all below a split root)
+        assert d.n_guards >= 8 and sorted(d.frames[f].parent for f in range(d.n_frames)) == [-1, 0, 0, 1, 1, 1]
     else:   # (five more frames: the two untouched parts of the sword with a moved face each, a leg of the other mesh and the octant in it that holds the moved face ... and the group)
         assert d.n_frames >= 12 and max(d.frames[f].parent for f in range(d.n_frames)) > 5
