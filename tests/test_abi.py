@@ -146,3 +146,19 @@ def test_corrupted_descriptions_are_rejected_without_a_device(pt):
         assert st in (1, 2) and word in msg, (st, msg, word)
     st, msg = attempt(lambda d, p, f: None)
     assert st == (0 if pt.device_count() > 0 else 3), msg
+    # a split root whose occurrences name a frame that lies inside another frame: rays reach such a frame through the
+    # entries of the frame at the top of its chain, it has none of its own
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from nested_ops import apply_split
+    hs = pt.HostScene(pt.SDF_DIR + "/split_root.sdf")
+    apply_split(hs, None)
+    d = type(hs.desc.contents).from_buffer_copy(hs.desc.contents)
+    inner = next(f for f in range(1, d.n_frames) if d.frames[f].parent > 0)
+    occ = (pt.PtxOccurrence * d.n_occurrences)(*[d.occurrences[k] for k in range(d.n_occurrences)])
+    k = next(k for k in range(d.n_occurrences) if occ[k].prim == -1)
+    occ[k].frame = inner
+    d.occurrences = occ
+    out = ctypes.c_void_p()
+    st = L.ptx_scene_create(ctypes.byref(d), 0, 0, ctypes.byref(out))
+    assert st == 1 and f"occurrence {k}" in L.ptx_last_error().decode()
