@@ -36,7 +36,7 @@ extern "C" {
 typedef enum PtxStatus {
 	PTX_OK = 0,
 	PTX_ERR_INVALID = 1,     /* bad argument / malformed scene description            */
-	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (a sphere, box or moved triangle below an untransformed Composite inside a transformed one; transformed Composites more than 8 deep) */
+	PTX_ERR_UNSUPPORTED = 2, /* scene shape this library does not flatten (a sphere, box or moved triangle below an untransformed Composite inside a transformed one; transformed Composites more than 32 deep) */
 	PTX_ERR_DEVICE = 3,      /* HIP call failed, or no gfx950 device                  */
 	PTX_ERR_OVERFLOW = 4,    /* a ray queue filled up: result discarded, see message  */
 	PTX_ERR_NOMEM = 5
@@ -67,7 +67,7 @@ typedef struct PtxCamera {
  * find_child(..)->translate / rotate / scale, composite.cpp:112-114, :168-181).  Octants and OBJ
  * sub-objects with the identity transform are NOT frames; they only show up as `levels`.
  * A frame may lie inside another frame (a transformed Composite below a transformed Composite),
- * at most 8 deep; Composite::intersect then tests one bounds_ box and changes coordinates once
+ * at most 32 deep; Composite::intersect then tests one bounds_ box and changes coordinates once
  * per level, and so does the library.  Frames are listed depth first: a frame's parent comes
  * before it.
  *   bounds_min/max  the frame's bounds_ box, in the space of the frame it lies in (as the

@@ -915,7 +915,17 @@ int oracle_add_group(void* s, const char* name, int n, const int* kinds, const f
 	};
 	const std::vector<std::string> names = split(child_names), mats = split(material_names);
 	if ((int) names.size() != n || (int) mats.size() != n) return 1;
-	auto g = std::make_shared<Composite>(std::string(name));
+	// "a/b/name": into Composite b inside Composite a under the root
+	std::vector<std::shared_ptr<Composite>> above{sc->root};
+	std::string own(name ? name : "");
+	for (size_t cut; (cut = own.find('/')) != std::string::npos; own = own.substr(cut + 1)) {
+		auto it = above.back()->children.find(own.substr(0, cut));
+		if (it == above.back()->children.end()) return 1;
+		auto next = std::dynamic_pointer_cast<Composite>(it->second);
+		if (!next) return 1;
+		above.push_back(next);
+	}
+	auto g = std::make_shared<Composite>(own);
 	for (int i = 0; i < n; ++i) {
 		const float* p = params + 7 * i;
 		auto it = sc->materials.find(mats[(size_t) i]);
@@ -924,8 +934,8 @@ int oracle_add_group(void* s, const char* name, int n, const int* kinds, const f
 		else g->add_child(std::make_shared<Box>(V3{p[0], p[1], p[2]}, V3{p[3], p[4], p[5]}, names[(size_t) i], it->second));
 	}
 	g->build_octree();
-	sc->root->add_child(g);
-	sc->root->build_octree();
+	above.back()->add_child(g);
+	for (size_t k = above.size(); k-- > 0;) above[k]->build_octree();
 	sc->rank.clear();
 	sc->leaves.clear();
 	sc->leaf_path.clear();

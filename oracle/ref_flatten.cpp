@@ -249,7 +249,17 @@ int ref_add_group(void* scene_ptr, const char* name, int n, const int* kinds, co
 	};
 	const std::vector<std::string> names = split(child_names), mats = split(material_names);
 	if ((int) names.size() != n || (int) mats.size() != n) return 1;
-	auto g = std::make_shared<Composite>(std::string(name));
+	// "a/b/name": into Composite b inside Composite a under the root
+	std::vector<std::shared_ptr<Composite>> above{scene->root};
+	std::string own(name ? name : "");
+	for (size_t cut; (cut = own.find('/')) != std::string::npos; own = own.substr(cut + 1)) {
+		auto it = above.back()->children_.find(own.substr(0, cut));
+		if (it == above.back()->children_.end()) return 1;
+		auto next = std::dynamic_pointer_cast<Composite>(it->second);
+		if (!next) return 1;
+		above.push_back(next);
+	}
+	auto g = std::make_shared<Composite>(own);
 	for (int i = 0; i < n; ++i) {
 		const float* p = params + 7 * i;
 		auto it = scene->materials.find(mats[(size_t) i]);
@@ -258,8 +268,8 @@ int ref_add_group(void* scene_ptr, const char* name, int n, const int* kinds, co
 		else g->add_child(std::make_shared<Box>(glm::vec3{p[0], p[1], p[2]}, glm::vec3{p[3], p[4], p[5]}, names[(size_t) i], it->second));
 	}
 	g->build_octree();
-	scene->root->add_child(g);
-	scene->root->build_octree();
+	above.back()->add_child(g);
+	for (size_t k = above.size(); k-- > 0;) above[k]->build_octree();
 	return 0;
 }
 // scene.root->find_child(a)->find_child(b)...->translate / rotate / scale with the reference's own methods

@@ -62,7 +62,15 @@ int pth_scene_add_group(void* h, const char* name, int n, const int* kinds, cons
 		};
 		const std::vector<std::string> names = split(child_names), mats = split(material_names);
 		if ((int) names.size() != n || (int) mats.size() != n) throw SceneError{"add_group: n names and n materials expected"};
-		auto g = std::make_shared<Composite>(name);
+		// "a/b/name": the new Composite goes into Composite b inside Composite a under the root
+		std::vector<std::shared_ptr<Composite>> above{hs->scene.root};
+		std::string own(name ? name : "");
+		for (size_t cut; (cut = own.find('/')) != std::string::npos; own = own.substr(cut + 1)) {
+			std::shared_ptr<Shape> next = above.back()->find_child(own.substr(0, cut));
+			if (next->kind() != Shape::Kind::composite) throw SceneError{"'" + next->get_name() + "' has no children"};
+			above.push_back(std::static_pointer_cast<Composite>(next));
+		}
+		auto g = std::make_shared<Composite>(own);
 		for (int i = 0; i < n; ++i) {
 			const float* p = params + 7 * i;
 			std::shared_ptr<Material> m = hs->scene.find_mat(mats[(size_t) i]);
@@ -70,8 +78,8 @@ int pth_scene_add_group(void* h, const char* name, int n, const int* kinds, cons
 			else g->add_child(std::make_shared<Box>(vec3{p[0], p[1], p[2]}, vec3{p[3], p[4], p[5]}, names[(size_t) i], m));
 		}
 		g->build_octree();
-		hs->scene.root->add_child(g);
-		hs->scene.root->build_octree();
+		above.back()->add_child(g);
+		for (size_t k = above.size(); k-- > 0;) above[k]->build_octree();  // (bounds of everything above, innermost first)
 		hs->flat = flatten_scene(hs->scene);
 		return 0;
 	} catch (SceneError const& e) {

@@ -613,7 +613,7 @@ __device__ __forceinline__ bool root_walk(const DevScene& S, f3 o, f3 d, const R
 // The ray goes down the chain of frames from the root's child to `f`: at every level the reference's bounds test in
 // the space the ray has there, then the level's own inverse.  false: the ray does not get as far as the inside of `f`.
 // (`f` is the same in every lane; the chain is short, so the frame above is looked up again rather than kept)
-constexpr int kMaxNest = 8;
+constexpr int kMaxNest = 32;
 template <class TC>
 __device__ __forceinline__ bool enter_nested(const DevScene& S, int f, f3 o, f3 d, f3& lo, f3& ld, TC& tc) {
 	int depth = 0;

@@ -82,3 +82,25 @@ def apply_split(impl, scene):
     else:
         impl.add_group(scene, *SPLIT_GROUP)
     apply_ops(impl, scene, SPLIT_GROUP_OPS)
+
+
+# Twelve Composites of the caller's own one inside the other under the root of nested.sdf, a sphere or a box in each,
+# every one of them turned and shifted a little: a chain of frames deeper than any octree of a loaded mesh gives.
+DEEP_LEVELS = 12
+
+
+def apply_deep(impl, scene):
+    """NESTED_OPS, then the chain t0/t1/.../t11, every level moved as soon as it is there (the Composites above get
+    their bounds from what they hold when the next one is added; the moves after the last one do not reach them)"""
+    apply_ops(impl, scene)
+    args = () if scene is None else (scene,)
+    path = ""
+    for k in range(DEEP_LEVELS):
+        path = f"{path}/t{k}" if path else "t0"
+        leaf = ("sphere", f"ds{k}", (0.35 * k, 0.0, 0.0, 0.3), ("glass", "red", "mirror", "white")[k % 4]) if k % 2 == 0 else \
+               ("box", f"db{k}", (0.35 * k - 0.25, -0.25, -0.25, 0.35 * k + 0.25, 0.25, 0.25), ("glass", "red", "mirror", "white")[k % 4])
+        impl.add_group(*args, path, [leaf])
+        impl.transform_child(*args, path, "rotate", 0.0, 0.0, 0.12)
+        impl.transform_child(*args, path, "translate", 0.05, 0.1, 0.0)
+    impl.transform_child(*args, "t0", "translate", -3.0, 1.0, -9.0)
+    impl.transform_child(*args, "t0", "scale", 1.2, 1.0, 1.1)

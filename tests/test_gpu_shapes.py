@@ -582,3 +582,42 @@ def test_moved_parts_below_a_split_root(pt, port):
         assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
     ds.close()
     port.free(s)
+
+
+def test_twelve_composites_one_inside_the_other(pt, port):
+    """A chain of frames deeper than the octree of any loaded mesh gives (a face moved at the bottom of the big mesh's
+    octree sits seven frames deep): twelve Composites of the caller's own one inside the other under the root of
+    nested.sdf, each turned and shifted, a sphere or a box in each (tests/nested_ops.py, apply_deep; the reference and
+    the oracle agree on this scene bit for bit, tests/test_oracle.py).  Every level is hit, every hit is the oracle's:
+    identity exact, distance, position, normal and ray direction bit-identical; images at the usual bar."""
+    from nested_ops import DEEP_LEVELS, apply_deep
+    from oracle_lib import random_rays
+    path = pt.SDF_DIR + "/nested.sdf"
+    hs = pt.HostScene(path)
+    apply_deep(hs, None)
+    s = port.load(path)
+    apply_deep(port, s)
+    assert hs.prim_names() == port.leaf_names(s)
+    d = hs.desc.contents
+    depth = [0] * d.n_frames
+    for f in range(1, d.n_frames):
+        depth[f] = depth[d.frames[f].parent] + 1
+    assert max(depth) == DEEP_LEVELS
+    ds = pt.DeviceScene(hs, 0, 1 << 28)
+    o1, d1 = port.primary_rays(s, 480, 320, 1)
+    o2, d2 = random_rays(40000, 7, lo=(-8, -1, -20), hi=(8, 10, 4))
+    o, dd = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    a, b = ds.intersect(o, dd), port.intersect(s, o, dd)
+    assert np.array_equal(a["prim"], b["rank"])
+    m = b["hit"]
+    names = np.array(hs.prim_names())[b["rank"][m]]
+    for k in range(DEEP_LEVELS):
+        assert (names == ("ds%d" if k % 2 == 0 else "db%d") % k).sum() > 50, k
+    for k in ("t", "pos", "normal", "raydir"):
+        assert beq(a[k][m], b[k][m]), k
+    ref = port.render(s, 160, 100, 2, 4)
+    for pipeline in PIPELINES:
+        r = ds.render_image(160, 100, 2, 4, pipeline=pipeline)
+        assert_image_close(r["color"], ref["color"], r["rgb"], ref["rgb"])
+    ds.close()
+    port.free(s)

@@ -188,7 +188,7 @@ def test_oracle_equals_reference_on_hand_written_fixtures(port, tmp_path, name):
     assert np.array_equal(ia["rgb"], ib["rgb"]) and same_bits_or_both_nan(ia["color"], ib["color"])
 
 
-@pytest.mark.parametrize("grouped", [False, True, "split_root"])
+@pytest.mark.parametrize("grouped", [False, True, "split_root", "deep"])
 def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     """nested.sdf with parts of its two loaded meshes moved after load_scene (tests/nested_ops.py:
     root->find_child(..)->find_child(..)->translate / rotate / scale with the reference's own methods):
@@ -198,13 +198,14 @@ def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     the chain of frames in it.  grouped: in addition a Composite of the caller's own with spheres and boxes in it, moved as
     a whole and member by member, and single faces of a moved mesh part moved once more (leaves that are not plain
     triangles inside transformed Composites).  split_root: the same kinds of moves on split_root.sdf, where the mesh is
-    reached through the octants of a root with more than 64 children.  Container-only (needs oracle/_ref/libref.so)."""
+    reached through the octants of a root with more than 64 children.  deep: twelve Composites of the caller's own one
+    inside the other, each moved, a sphere or a box in each.  Container-only (needs oracle/_ref/libref.so)."""
     import importlib
     import sys
     from conftest import REPO
-    from nested_ops import apply_group, apply_ops, apply_split
+    from nested_ops import apply_deep, apply_group, apply_ops, apply_split
     if grouped:
-        apply_ops = apply_split if grouped == "split_root" else apply_group     # noqa: F811
+        apply_ops = {"split_root": apply_split, "deep": apply_deep}.get(grouped, apply_group)     # noqa: F811
     from oracle_lib import Reference, SDF_DIR, random_rays
     if not Reference.available():
         pytest.skip("oracle/_ref/libref.so absent")
@@ -241,6 +242,8 @@ def test_oracle_equals_reference_on_moved_mesh_parts(port, grouped):
     d = hs.desc.contents
     if not grouped:
         assert sorted(d.frames[f].parent for f in range(d.n_frames)) == [-1, 0, 0, 1, 1, 4, 4]
+    elif grouped == "deep":
+        assert max(d.frames[f].parent for f in range(d.n_frames)) >= 12
     elif grouped == "split_root":   # (the sword with three of its parts as frames inside it, and the group; all below a split root)
         assert d.n_guards >= 8 and sorted(d.frames[f].parent for f in range(d.n_frames)) == [-1, 0, 0, 1, 1, 1]
     else:   # (five more frames: the two untouched parts of the sword with a moved face each, a leg of the other mesh and the octant in it that holds the moved face ... and the group)
