@@ -332,6 +332,18 @@ int ptx_device_count(void) {
 	return n;
 }
 
+// entries of the traversal stack a launch asks LDS for: what the scene's deepest tree needs
+// (PTX_WALK_ENTRIES="a,b,c,d" in the environment: at least that many for the closest-hit kernel of depth 0, of the deeper
+// depths, the shadow kernel of depth 0, of the deeper depths - for measurements of the waves a compute unit holds)
+static int stack_entries(const PtxScene* sc, int which = -1) {
+	static int at_least[4] = {-1, 0, 0, 0};
+	if (at_least[0] < 0) {
+		at_least[0] = 0;
+		if (const char* e = getenv("PTX_WALK_ENTRIES")) sscanf(e, "%d,%d,%d,%d", &at_least[0], &at_least[1], &at_least[2], &at_least[3]);
+	}
+	return std::max(sc->max_depth, which < 0 ? 0 : at_least[which]);
+}
+
 PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_bytes, PtxScene** out) {
 	if (!D || !out) return fail(PTX_ERR_INVALID, "desc/out is NULL");
 	*out = nullptr;
@@ -1106,7 +1118,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		if (!staged) {
 			HIP_TRY(tick(0, d, true));
 			auto kern = d == 0 ? (ip ? k_bounce<true, true> : k_bounce<true, false>) : (ip ? k_bounce<false, true> : k_bounce<false, false>);
-			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), walk_lds_bytes(stack_entries(sc), false), stream, A);
 			HIP_TRY(tick(0, d, false));
 			launches += 1;
 			return PTX_OK;
@@ -1137,7 +1149,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 				return d == 0 ? (rb ? k_trace<true, true, TC> : k_trace<true, false, TC>) : (rb ? k_trace<false, true, TC> : k_trace<false, false, TC>);
 			};
 			auto kern = count_tests ? pick(TestCount{}) : pick(NoCount{});
-			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), walk_lds_bytes(stack_entries(sc, d == 0 ? 0 : 1), d != 0), stream, A);
 			PTX_TL(0, d);
 		}
 		HIP_TRY(tick(0, d, false));
@@ -1160,7 +1172,7 @@ PtxStatus render_accumulate(PtxScene* sc, const WorkMem& M, const PtxRenderParam
 		if (sc->dev.n_lights > 0) {
 			HIP_TRY(tick(2, d, true));
 			auto kern = count_tests ? (rb ? k_shadow<true, TestCount> : k_shadow<false, TestCount>) : (rb ? k_shadow<true, NoCount> : k_shadow<false, NoCount>);
-			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), 0, stream, A);
+			hipLaunchKernelGGL(kern, walk_grid, dim3(kWalkBlock), walk_lds_bytes(stack_entries(sc, d == 0 ? 2 : 3), false), stream, A);
 			PTX_TL(2, d);
 			HIP_TRY(tick(2, d, false));
 			launches += 1;
@@ -1501,7 +1513,7 @@ static PtxStatus run_intersect(PtxScene* sc, IntersectArgs& A, int64_t n, int32_
 	A.rdir = static_cast<float*>(d_rd);
 	unsigned grid = (unsigned) std::min<int64_t>((n + kWalkBlock - 1) / kWalkBlock, (int64_t) sc->grid * (kBlock / kWalkBlock));
 	if (grid == 0) grid = 1;
-	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards || sc->dev.nested ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kWalkBlock), 0, nullptr, A);
+	hipLaunchKernelGGL(sc->dev.root_bvh || sc->dev.n_guards || sc->dev.nested ? k_intersect<true> : k_intersect<false>, dim3(grid), dim3(kWalkBlock), walk_lds_bytes(stack_entries(sc), false), nullptr, A);
 	TRY_C(hipGetLastError());
 	TRY_C(hipDeviceSynchronize());
 	if (prim) TRY_C(hipMemcpy(prim, d_prim, (size_t) n * 4, hipMemcpyDeviceToHost));

@@ -31,7 +31,14 @@ constexpr int kShadeBlock = PTX_SHADE_BLOCK;
 #ifndef PTX_MIN_WAVES
 #define PTX_MIN_WAVES 2  // waves per SIMD the bounce kernel's register budget is sized for
 #endif
-constexpr int kStack = 30;  // entries per lane; a BVH of depth d needs d - 1 (kBvhMaxDepth = 30), and five blocks of 30 KiB fit the 160 KiB of a CU
+// Traversal stack: entries per lane, in LDS.  A BVH whose deepest leaf lies d levels below the root needs d; the deepest
+// the builder makes is kBvhMaxDepth = 30.  The kernels that walk take the stack as dynamic LDS sized for the deepest
+// tree of the scene at hand (walk_lds_bytes), because the stack is what limits the waves a compute unit holds, and these
+// kernels run the faster the more waves there are to fill each other's waits (measured on the mesh scene, whose trees
+// need 20 entries, ms per image: closest hit of depth 0 with 12 / 16 / 22 / 28 waves per compute unit 45.5 / 37.0 / 32.3 /
+// 28.5, of the deeper depths with 16 / 20 / 22 / 24 waves 72.9 / 70.7 / 65.7 / 62.3, shadow rays with 16 / 20 / 24 waves
+// 64.1 / 60.1 / 52.4; the image 272.9 with 30 entries everywhere, 250.3 as it is now).
+constexpr int kStack = 30;
 static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
 constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
 constexpr unsigned kMaxBounces = 63;
@@ -1582,7 +1589,7 @@ __device__ __forceinline__ void stat_add_tests<NoCount>(unsigned long long*, int
 // ---- fused pipeline: one kernel per depth -----------------------------------------------
 template <bool PRIMARY, bool INTPOW>
 __global__ __launch_bounds__(kWalkBlock, PTX_MIN_WAVES) void k_bounce(BounceArgs A) {
-	__shared__ int lds_stack[kStack * kWalkBlock];
+	extern __shared__ int lds_stack[];  // walk_lds_bytes
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
 	const unsigned wave = wave_id<kWalkBlock>();
@@ -1647,7 +1654,17 @@ __device__ __forceinline__ int hit_where(const Hit& h) {
 }
 // (measured again with 32 768 segments per launch, ms per image on the mesh scene: walk on the spot from 24 lanes on 280.3,
 // from 40 on 278.8, from 56 on 280.1, never 289.9; a ring of 192 rays 285.9)
-constexpr unsigned kRing = 128;    // parked rays per wave
+// (96 rays, not 128: the closest-hit kernel of the deeper depths then fits 24 waves into a compute unit instead of 22,
+// 65.7 -> 62.3 ms per image; 80: the same.  A step that would overflow the ring walks what is parked first.)
+#ifndef PTX_RING
+#define PTX_RING 96
+#endif
+constexpr unsigned kRing = PTX_RING;    // parked rays per wave
+// dynamic LDS of a launch of a kernel that walks: a stack of `entries` per lane, and for the closest-hit kernel of the
+// staged pipeline the rings in front of it
+constexpr size_t walk_lds_bytes(int entries, bool with_ring) {
+	return (size_t) (entries < 2 ? 2 : entries) * kWalkBlock * sizeof(int) + (with_ring ? (kWalkBlock / 64) * kRing * sizeof(float4) : 0);
+}
 constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
 #ifndef PTX_PRIMARY_WAVES
 #define PTX_PRIMARY_WAVES 5
@@ -1656,10 +1673,9 @@ template <bool PRIMARY, bool RB, class TC>
 __global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
-	__shared__ int lds_stack[kStack * kWalkBlock];
-	__shared__ float4 ring_mem[(kWalkBlock / 64) * kRing];
-	int* stk = lds_stack + threadIdx.x;
-	volatile float4* ring = ring_mem + (threadIdx.x >> 6) * kRing;
+	extern __shared__ float4 walk_lds[];  // the rings of the workgroup's waves, then the stack (walk_lds_bytes); primary rays never park: no rings
+	int* stk = reinterpret_cast<int*>(walk_lds + (PRIMARY ? 0 : (kWalkBlock / 64) * kRing)) + threadIdx.x;
+	volatile float4* ring = walk_lds + (threadIdx.x >> 6) * kRing;
 	const unsigned lane = lane_id();
 	const unsigned wave = PRIMARY ? wave_id<kWalkBlock>() : segment_of(A.order, wave_id<kWalkBlock>());
 	const WaveTimer timer(wave_id<kWalkBlock>(), wave);
@@ -2104,12 +2120,12 @@ __global__ __launch_bounds__(kShadeBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES
 // unblocked ray adds its contribution to its pixel
 template <bool RB, class TC>
 #ifndef PTX_SHADOW_WAVES
-#define PTX_SHADOW_WAVES 5
+#define PTX_SHADOW_WAVES 6  // (80 registers instead of the 81 the compiler takes unasked: a sixth wave per SIMD, 55.4 -> 51.9 ms per image; 7: no further gain)
 #endif
 __global__ __launch_bounds__(kWalkBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
-	__shared__ int lds_stack[kStack * kWalkBlock];
+	extern __shared__ int lds_stack[];  // walk_lds_bytes
 	int* stk = lds_stack + threadIdx.x;
 	const unsigned lane = lane_id();
 	const unsigned wave = segment_of(A.order, wave_id<kWalkBlock>());
@@ -2301,7 +2317,7 @@ struct IntersectArgs {
 };
 template <bool RB>
 __global__ __launch_bounds__(kWalkBlock) void k_intersect(IntersectArgs A) {
-	__shared__ int lds_stack[kStack * kWalkBlock];
+	extern __shared__ int lds_stack[];  // walk_lds_bytes
 	int* stk = lds_stack + threadIdx.x;
 	for (long long i = (long long) blockIdx.x * kWalkBlock + threadIdx.x; i < A.n; i += (long long) gridDim.x * kWalkBlock) {
 		f3 o, d;
