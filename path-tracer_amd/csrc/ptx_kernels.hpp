@@ -35,9 +35,10 @@ constexpr int kShadeBlock = PTX_SHADE_BLOCK;
 // the builder makes is kBvhMaxDepth = 30.  The kernels that walk take the stack as dynamic LDS sized for the deepest
 // tree of the scene at hand (walk_lds_bytes), because the stack is what limits the waves a compute unit holds, and these
 // kernels run the faster the more waves there are to fill each other's waits (measured on the mesh scene, whose trees
-// need 20 entries, ms per image: closest hit of depth 0 with 12 / 16 / 22 / 28 waves per compute unit 45.5 / 37.0 / 32.3 /
-// 28.5, of the deeper depths with 16 / 20 / 22 / 24 waves 72.9 / 70.7 / 65.7 / 62.3, shadow rays with 16 / 20 / 24 waves
-// 64.1 / 60.1 / 52.4; the image 272.9 with 30 entries everywhere, 250.3 as it is now).
+// need 20 entries; ms per image, LDS per wave -> waves that fit 160 KiB: closest hit of depth 0 13.0 KiB -> 12 waves 45.5,
+// 9.5 KiB -> 16 waves 37.0, 7.0 KiB -> 22 waves 32.3, 5.0 KiB -> its registers' 28 waves 28.5; of the deeper depths
+// 8.0 KiB -> 20 waves 70.7, 7.0 KiB -> 22 waves 65.7, 6.5 KiB -> 24 waves 62.3; shadow rays 10 KiB 64.1, 8 KiB 60.1, 5 KiB
+// 52.4; the image 272.9 with 30 entries everywhere, 250.3 as it is now).
 constexpr int kStack = 30;
 static_assert(kStack >= ptx::kBvhMaxDepth, "stack must cover the deepest BVH leaf");
 constexpr int kMaxDepthSlots = 16;             // per-depth statistics (deeper levels share the last slot)
@@ -2120,7 +2121,7 @@ __global__ __launch_bounds__(kShadeBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES
 // unblocked ray adds its contribution to its pixel
 template <bool RB, class TC>
 #ifndef PTX_SHADOW_WAVES
-#define PTX_SHADOW_WAVES 6  // (80 registers instead of the 81 the compiler takes unasked: a sixth wave per SIMD, 55.4 -> 51.9 ms per image; 7: no further gain)
+#define PTX_SHADOW_WAVES 6  // (80 registers instead of the 81 the compiler takes unasked: a sixth wave per SIMD; -6 % under the kernel tracer, nothing without it; 7: the same)
 #endif
 __global__ __launch_bounds__(kWalkBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);

@@ -41,7 +41,7 @@ for k in names:
     tot_t += t
     tot_b += gb
     print('| `%s` | %.1f | %.1f GB (%.1f TB/s) | %.0f %% | %.0f %% | %.0f %% | %.0f %% | %.1f TFLOP/s |' % (
-        k, t * 1e3, gb, gb / t / 1e3, 100 * c['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles,
+        k, t * 1e3, gb, gb / t / 1e3, 100 * c['SQ_ACTIVE_INST_VALU'] * 2 / simd_cycles,   # (a SIMD takes a 64-wide vector instruction in two cycles)
         100 * c['SQ_THREAD_CYCLES_VALU'] / (c['SQ_ACTIVE_INST_VALU'] * 64), 100 * c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'],
         100 * (1 - c['TCP_TCC_READ_REQ_sum'] / c['TCP_TOTAL_CACHE_ACCESSES_sum']),
         (2 * c['SQ_INSTS_VALU_FMA_F32'] + c['SQ_INSTS_VALU_MUL_F32']) * 64 / t / 1e12))
