@@ -1666,7 +1666,10 @@ constexpr unsigned kRing = PTX_RING;    // parked rays per wave
 constexpr size_t walk_lds_bytes(int entries, bool with_ring) {
 	return (size_t) (entries < 2 ? 2 : entries) * kWalkBlock * sizeof(int) + (with_ring ? (kWalkBlock / 64) * kRing * sizeof(float4) : 0);
 }
-constexpr unsigned kWalkNow = 40;  // lanes of a step that reach a mesh from which the step walks on the spot
+#ifndef PTX_WALK_NOW
+#define PTX_WALK_NOW 40
+#endif
+constexpr unsigned kWalkNow = PTX_WALK_NOW;  // lanes of a step that reach a mesh from which the step walks on the spot
 #ifndef PTX_PRIMARY_WAVES
 #define PTX_PRIMARY_WAVES 5
 #endif
