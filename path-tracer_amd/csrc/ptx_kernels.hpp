@@ -1670,11 +1670,14 @@ constexpr size_t walk_lds_bytes(int entries, bool with_ring) {
 #define PTX_WALK_NOW 40
 #endif
 constexpr unsigned kWalkNow = PTX_WALK_NOW;  // lanes of a step that reach a mesh from which the step walks on the spot
+#ifndef PTX_TRACE_WAVES_RB
+#define PTX_TRACE_WAVES_RB 4
+#endif
 #ifndef PTX_PRIMARY_WAVES
 #define PTX_PRIMARY_WAVES 5
 #endif
 template <bool PRIMARY, bool RB, class TC>
-__global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : 4) void k_trace(BounceArgs A_) {
+__global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : ((!PRIMARY && RB) ? PTX_TRACE_WAVES_RB : 4)) void k_trace(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
 	extern __shared__ float4 walk_lds[];  // the rings of the workgroup's waves, then the stack (walk_lds_bytes); primary rays never park: no rings
@@ -2123,10 +2126,13 @@ __global__ __launch_bounds__(kShadeBlock, (PRIMARY && INTPOW) ? PTX_SHADE0_WAVES
 // find_light_block for every queued shadow ray (framework/renderer.cpp:148, :168-175); an
 // unblocked ray adds its contribution to its pixel
 template <bool RB, class TC>
+#ifndef PTX_SHADOW_WAVES_RB
+#define PTX_SHADOW_WAVES_RB 6  // (the variant for a frame 0 with a tree of its own: 80 registers and 20 bytes of scratch; on a room with 60 shapes in it 167.0 -> 160.3 ms against five waves without scratch)
+#endif
 #ifndef PTX_SHADOW_WAVES
 #define PTX_SHADOW_WAVES 6  // (80 registers instead of the 81 the compiler takes unasked: a sixth wave per SIMD; -6 % under the kernel tracer, nothing without it; 7: the same)
 #endif
-__global__ __launch_bounds__(kWalkBlock, PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
+__global__ __launch_bounds__(kWalkBlock, RB ? PTX_SHADOW_WAVES_RB : PTX_SHADOW_WAVES) void k_shadow(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
 	extern __shared__ int lds_stack[];  // walk_lds_bytes
