@@ -47,11 +47,10 @@ constexpr unsigned kMaxBounces = 63;
 #ifndef PTX_MAX_SEG
 #define PTX_MAX_SEG 32768
 #endif
-// most segments = waves of a grid: eight rounds of the waves an MI355X keeps resident at four per SIMD.  Measured on the
-// mesh scene (1920x1080, 1024 spp, 32 GiB of queues), ms per image: 16 384 segments 290.3, 32 768 segments 285.6 (a
-// launch ends with its last waves, and shorter waves make a shorter end: shadow kernel 62.7 -> 58.7, shading 77.4 ->
-// 75.9, primary closest hit 35.8 -> 34.0; the closest-hit kernel of the deeper depths, whose waves walk their parked
-// rays once more at their end, 85.1 -> 88.1), 65 536 segments 306.
+// most segments = waves of a grid: five to eight rounds of the waves an MI355X keeps resident (six / four per SIMD in the
+// walking / shading kernels).  Measured on the mesh scene (1920x1080, 1024 spp, 32 GiB of queues), ms per image: 16 384
+// segments 264.3, 32 768 segments 250.8 (a launch ends with its last waves, and shorter waves make a shorter end),
+// 65 536 segments 254.3 (with four waves per SIMD in the walking kernels it was 290.3 / 285.6 / 306).
 constexpr unsigned kMaxSeg = PTX_MAX_SEG;
 constexpr size_t count_bytes(unsigned max_seg) { return ((size_t) 3 * (kMaxBounces + 2) + 1) * max_seg * sizeof(unsigned); }  // per depth: ray, shadow-ray and hit counts of every segment; one more row: the order the segments of the depths > 0 are taken in
 
