@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--aa", type=int, default=32)
     ap.add_argument("--bounces", type=int, default=5)
-    ap.add_argument("--queue-gib", type=float, default=32.0, help="ray queue memory per GPU (the scene stays resident over all steps: 32 GiB is where larger queues stop paying); 0 = the library's default, also 32 GiB")
+    ap.add_argument("--queue-gib", type=float, default=64.0, help="ray queue memory per GPU (the scene stays resident over all steps: 64 GiB is where larger queues stop paying); 0 = the library's default, also 64 GiB")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration; 0 skips it")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernel launches with HIP events")
     ap.add_argument("--no-census", action="store_true", help="skip the extra, untimed step that counts the tests")

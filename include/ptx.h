@@ -265,9 +265,9 @@ int ptx_device_count(void);
 
 /*
  * Validates and uploads a scene to `device`, builds the per-frame BVHs and allocates the
- * ray queues.  queue_bytes = HBM budget for the ray queues (0 = 32 GiB, or a third of the
+ * ray queues.  queue_bytes = HBM budget for the ray queues (0 = 64 GiB, or a third of the
  * memory the device has free at this moment if that is less; at least 96 MiB is taken; more
- * memory means fewer, larger kernel launches, never different results: 32 GiB is where the
+ * memory means fewer, larger kernel launches, never different results: 64 GiB is where the
  * gain ends, and the block costs the same few milliseconds to create and destroy at any size).
  * Replaces the per-thread Scene copies of framework/renderer.cpp:48.
  * A PtxScene owns its queues and counters: use it from one thread (one render) at a time;

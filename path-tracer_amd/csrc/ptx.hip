@@ -835,13 +835,14 @@ PtxStatus ptx_scene_create(const PtxSceneDesc* D, int device, uint64_t queue_byt
 
 	// ---- ray queue memory (48 B per ray); ptx_render_accumulate cuts it into queues
 	if (queue_bytes == 0) {
-		// 32 GiB, or a third of what the device has free now if that is less.  Measured on the mesh scene at
-		// 1920x1080, 1024 spp: 334 ms per image with 8 GiB, 314 with 16, 303 with 32, the same with 64 (more memory
+		// 64 GiB, or a third of what the device has free now if that is less.  Measured on the mesh scene at
+		// 1920x1080, 1024 spp: 276.4 ms per image with 16 GiB, 250.3 with 32, 245.0 with 64, 244.1 with 96 (more memory
 		// means fewer, larger launches); creating the scene takes 7 ms and destroying it 1 - 2 ms whatever the size
-		// (the block is mapped, not touched, until a render writes to it), so a one-image caller loses nothing.
+		// (the block is mapped, not touched, until a render writes to it), and a program that renders one image and
+		// ends takes the same 0.37 s with 32 and with 64 GiB: a one-image caller loses nothing.
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		queue_bytes = std::min<uint64_t>(free_b / 3, 32ull << 30);
+		queue_bytes = std::min<uint64_t>(free_b / 3, 64ull << 30);
 	}
 	uint64_t cap = queue_bytes / 48;
 	cap = std::min<uint64_t>(cap, 1ull << 33);  // 384 GiB: above any device; each queue is limited on its own (64 sub-queues of at most 2^25 records)
