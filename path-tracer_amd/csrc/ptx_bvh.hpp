@@ -36,7 +36,12 @@ struct Bvh {
 #define PTX_BVH_MAX_LEAF 4
 #endif
 constexpr int kBvhMaxLeaf = PTX_BVH_MAX_LEAF;
-constexpr int kBvhMaxDepth = 30;
+// (a lower cap makes shallower trees, a smaller traversal stack and room for more waves, but worse trees: on the mesh
+// scene, whose SAH trees come out 20 deep, a cap of 18 changed nothing and 16 cost the closest-hit kernels 3 %)
+#ifndef PTX_BVH_MAX_DEPTH
+#define PTX_BVH_MAX_DEPTH 30
+#endif
+constexpr int kBvhMaxDepth = PTX_BVH_MAX_DEPTH;
 
 // boxes must be finite.  Deterministic (no threading, no RNG).  max_leaf: most items per leaf (1 .. 8).
 Bvh build_bvh(std::vector<Aabb> const& boxes, int max_leaf = kBvhMaxLeaf);

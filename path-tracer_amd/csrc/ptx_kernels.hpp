@@ -1669,6 +1669,9 @@ constexpr size_t walk_lds_bytes(int entries, bool with_ring) {
 #define PTX_WALK_NOW 40
 #endif
 constexpr unsigned kWalkNow = PTX_WALK_NOW;  // lanes of a step that reach a mesh from which the step walks on the spot
+#ifndef PTX_TRACE_WAVES
+#define PTX_TRACE_WAVES 4  // (the compiler takes 78 registers unasked: six waves; held to 72 for a seventh it spills: +11 % on that kernel)
+#endif
 #ifndef PTX_TRACE_WAVES_RB
 #define PTX_TRACE_WAVES_RB 4
 #endif
@@ -1676,7 +1679,7 @@ constexpr unsigned kWalkNow = PTX_WALK_NOW;  // lanes of a step that reach a mes
 #define PTX_PRIMARY_WAVES 5
 #endif
 template <bool PRIMARY, bool RB, class TC>
-__global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : ((!PRIMARY && RB) ? PTX_TRACE_WAVES_RB : 4)) void k_trace(BounceArgs A_) {
+__global__ __launch_bounds__(kWalkBlock, (PRIMARY && !RB) ? PTX_PRIMARY_WAVES : ((!PRIMARY && RB) ? PTX_TRACE_WAVES_RB : PTX_TRACE_WAVES)) void k_trace(BounceArgs A_) {
 	PTX_ARGS_IN_PLACE(ka);
 #define A (*(const BounceArgs*) ka)
 	extern __shared__ float4 walk_lds[];  // the rings of the workgroup's waves, then the stack (walk_lds_bytes); primary rays never park: no rings
